@@ -1,0 +1,320 @@
+"""CPU oracle: numpy restatement of the reference's speech -> SMPL-X body hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under `talkshow_amd/` or `nets/` may import this file;
+only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg do, and there
+only as the checker / the timed CPU baseline.  The product path is the HIP library.
+
+Parity pinning: every function here is checked in `tests/test_oracle_golden.py` against
+golden vectors that `tests/golden/make_golden.py` produced by running the reference's own
+PyTorch modules (imported from /root/reference in the build container) on the same seeded
+synthetic checkpoints.  The reference ships no tests / known-answer vectors of its own
+(SURVEY.md §4), so those generated fixtures are the pin.
+
+All tensors follow the reference's layouts (channels-first (B, C, L) / (B, C, H, W)) so each
+function can be read next to the file:line it restates.  fp32 throughout, int64 codes.
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+# ----------------------------------------------------------------------------------------------
+# primitives (torch.nn.functional semantics)
+# ----------------------------------------------------------------------------------------------
+
+def conv1d(x, w, b=None, stride=1, padding=0):
+    """nn.Conv1d: x (B,Cin,L), w (Cout,Cin,K) -> (B,Cout,Lout)."""
+    B, C, L = x.shape
+    O, C2, K = w.shape
+    assert C == C2
+    if padding:
+        x = np.pad(x, ((0, 0), (0, 0), (padding, padding)))
+    Lout = (x.shape[2] - K) // stride + 1
+    out = np.zeros((B, O, Lout), F32)
+    for k in range(K):
+        xs = x[:, :, k:k + stride * (Lout - 1) + 1:stride]          # (B,C,Lout)
+        out += np.matmul(np.ascontiguousarray(w[:, :, k])[None], np.ascontiguousarray(xs))
+    if b is not None:
+        out += b[None, :, None]
+    return out
+
+
+def conv_transpose1d(x, w, b=None, stride=2, padding=1):
+    """nn.ConvTranspose1d: x (B,Cin,L), w (Cin,Cout,K) -> (B,Cout,(L-1)*stride-2*padding+K)."""
+    B, C, L = x.shape
+    C2, O, K = w.shape
+    assert C == C2
+    full = np.zeros((B, O, (L - 1) * stride + K), F32)
+    for k in range(K):
+        full[:, :, k:k + stride * (L - 1) + 1:stride] += np.matmul(np.ascontiguousarray(w[:, :, k].T)[None], x)
+    out = full[:, :, padding:full.shape[2] - padding]
+    if b is not None:
+        out = out + b[None, :, None]
+    return out.astype(F32)
+
+
+def batchnorm_eval(x, sd, prefix, eps=1e-5):
+    """nn.BatchNorm1d in eval mode."""
+    g, be = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    m, v = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    inv = (g / np.sqrt(v + F32(eps))).astype(F32)
+    return (x - m[None, :, None]) * inv[None, :, None] + be[None, :, None]
+
+
+def leaky_relu(x, slope=0.2):
+    return np.where(x >= 0, x, x * F32(slope)).astype(F32)
+
+
+def relu(x):
+    return np.maximum(x, 0).astype(F32)
+
+
+def sigmoid(x):
+    return (1.0 / (1.0 + np.exp(-x))).astype(F32)
+
+
+# ----------------------------------------------------------------------------------------------
+# nets/spg/vqvae_modules.py
+# ----------------------------------------------------------------------------------------------
+
+def conv_norm_relu(x, sd, p, sample="none", residual=False):
+    """vqvae_modules.ConvNormRelu.forward (`vqvae_modules.py:167-172`), leaky=True, norm='bn'."""
+    if sample == "up":
+        out = conv_transpose1d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], 2, 1)
+    elif sample == "down":
+        out = conv1d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], 2, 1)
+    else:
+        out = conv1d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], 1, 1)
+    out = batchnorm_eval(out, sd, p + ".norm")
+    if residual:
+        if sample == "up":
+            out = out + conv_transpose1d(x, sd[p + ".residual_layer.weight"], sd[p + ".residual_layer.bias"], 2, 1)
+        else:
+            out = out + conv1d(x, sd[p + ".residual_layer.weight"], sd[p + ".residual_layer.bias"], 2, 1)
+    return leaky_relu(out)
+
+
+def res_cnr_stack(x, sd, p, layers=2):
+    """vqvae_modules.Res_CNR_Stack.forward (`vqvae_modules.py:205-212`)."""
+    h = x
+    for i in range(layers):
+        h = conv_norm_relu(h, sd, f"{p}._layers.{i}")
+    h = batchnorm_eval(conv1d(h, sd[p + ".conv.weight"], sd[p + ".conv.bias"], 1, 1), sd, p + ".norm")
+    return relu(h + x)
+
+
+def vq_get_code_indices(flat_x, emb):
+    """VectorQuantizerEMA.get_code_indices (`vqvae_modules.py:311-319`): same three-term formula."""
+    d = (np.sum(flat_x ** 2, axis=1, keepdims=True, dtype=F32)
+         + np.sum(emb ** 2, axis=1, dtype=F32)[None, :]
+         - F32(2.0) * np.matmul(flat_x, emb.T))
+    return np.argmin(d, axis=1).astype(np.int64)          # ties -> lowest index, as torch.argmin
+
+
+def vq_quantize(idx, emb):
+    """VectorQuantizerEMA.quantize (`vqvae_modules.py:321-323`)."""
+    return emb[idx]
+
+
+# ----------------------------------------------------------------------------------------------
+# nets/spg/vqvae_1d.py
+# ----------------------------------------------------------------------------------------------
+
+def _encoder_trunk(x, sd, p, layers=2):
+    h = conv_norm_relu(x, sd, p + "project")
+    h = res_cnr_stack(h, sd, p + "_enc_1", layers)
+    h = conv_norm_relu(h, sd, p + "_down_1", "down", True)
+    h = res_cnr_stack(h, sd, p + "_enc_2", layers)
+    h = conv_norm_relu(h, sd, p + "_down_2", "down", True)
+    h = res_cnr_stack(h, sd, p + "_enc_3", layers)
+    return h
+
+
+def audio_encoder(x, sd):
+    """vqvae_1d.AudioEncoder.forward (`vqvae_1d.py:27-34`): x (B,64,T) -> (B,256,T//4)."""
+    return _encoder_trunk(x, sd, "")
+
+
+def vq_encoder(x, sd):
+    """vqvae_1d.Encoder.forward (`vqvae_1d.py:84-92`): x (B,in_dim,T) -> z (B,64,T//4)."""
+    h = _encoder_trunk(x, sd, "encoder.")
+    return conv1d(h, sd["encoder.pre_vq_conv.weight"], sd["encoder.pre_vq_conv.bias"])
+
+
+def vq_decoder(e, sd):
+    """vqvae_1d.Decoder.forward (`vqvae_1d.py:139-149`): e (B,64,H) -> (B,out_dim,4H)."""
+    h = conv1d(e, sd["decoder.aft_vq_conv.weight"], sd["decoder.aft_vq_conv.bias"])
+    h = res_cnr_stack(h, sd, "decoder._dec_1")
+    h = conv_norm_relu(h, sd, "decoder._up_2", "up", True)
+    h = res_cnr_stack(h, sd, "decoder._dec_2")
+    h = conv_norm_relu(h, sd, "decoder._up_3", "up", True)
+    h = res_cnr_stack(h, sd, "decoder._dec_3")
+    return conv1d(h, sd["decoder.project.weight"], sd["decoder.project.bias"])
+
+
+def vqvae_encode(gt_poses, sd):
+    """VQVAE.encode (`vqvae_1d.py:196-199`) + VectorQuantizerEMA.forward eval branch (`vqvae_modules.py:274-286`).
+
+    gt_poses (B,T,in_dim) -> z (B,64,H), quantized e (B,64,H), latents (B,H) int64.
+    """
+    z = vq_encoder(np.ascontiguousarray(gt_poses.transpose(0, 2, 1)), sd)
+    B, C, H = z.shape
+    flat = np.ascontiguousarray(z.transpose(0, 2, 1)).reshape(-1, C)
+    idx = vq_get_code_indices(flat, sd["vq_layer.embeddings"])
+    e = vq_quantize(idx, sd["vq_layer.embeddings"]).reshape(B, H, C).transpose(0, 2, 1)
+    return z, np.ascontiguousarray(e), idx.reshape(B, H)
+
+
+def vqvae_decode(latents, sd):
+    """VQVAE.decode(latents=...) (`vqvae_1d.py:201-208`): latents (B,H) -> recon (B,out_dim,4H)."""
+    B, H = latents.shape
+    e = vq_quantize(latents.reshape(-1), sd["vq_layer.embeddings"]).reshape(B, H, -1).transpose(0, 2, 1)
+    return vq_decoder(np.ascontiguousarray(e), sd)
+
+
+def vqvae_forward(gt_poses, sd):
+    """VQVAE.forward eval branch (`vqvae_1d.py:184-189`): returns (e, x_recon (B,out_dim,T))."""
+    _, e, idx = vqvae_encode(gt_poses, sd)
+    return e, vq_decoder(e, sd), idx
+
+
+# ----------------------------------------------------------------------------------------------
+# nets/spg/gated_pixelcnn_v2.py
+# ----------------------------------------------------------------------------------------------
+
+def conv2d(x, w, b, pad_h, pad_w):
+    """nn.Conv2d stride 1: x (B,C,H,W), w (O,C,kh,kw) -> (B,O,H+2ph-kh+1,W+2pw-kw+1)."""
+    B, C, H, W = x.shape
+    O, _, kh, kw = w.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (pad_h, pad_h), (pad_w, pad_w)))
+    Ho, Wo = H + 2 * pad_h - kh + 1, W + 2 * pad_w - kw + 1
+    out = np.zeros((B, O, Ho, Wo), F32)
+    for i in range(kh):
+        for j in range(kw):
+            xs = xp[:, :, i:i + Ho, j:j + Wo].reshape(B, C, Ho * Wo)
+            out += np.matmul(np.ascontiguousarray(w[:, :, i, j])[None], xs).reshape(B, O, Ho, Wo)
+    return out + b[None, :, None, None]
+
+
+def gated_activation(x):
+    """GatedActivation.forward (`gated_pixelcnn_v2.py:20-22`)."""
+    a, g = np.split(x, 2, axis=1)
+    return (np.tanh(a) * sigmoid(g)).astype(F32)
+
+
+def causal_weights(sd, n_layers):
+    """make_causal (`gated_pixelcnn_v2.py:57-59`): layer 0 (mask 'A') zeroes the last kernel row / column."""
+    sd = dict(sd)
+    v = sd["layers.0.vert_stack.weight"].copy()
+    v[:, :, -1] = 0
+    h = sd["layers.0.horiz_stack.weight"].copy()
+    h[:, :, :, -1] = 0
+    sd["layers.0.vert_stack.weight"], sd["layers.0.horiz_stack.weight"] = v, h
+    return sd
+
+
+def gated_masked_conv2d(x_v, x_h, label, sd, p, kernel, residual):
+    """GatedMaskedConv2d.forward, bh_model=True (`gated_pixelcnn_v2.py:61-87`)."""
+    h = sd[p + ".class_cond_embedding.weight"][label]                       # (B, 2*dim)
+    h_vert = conv2d(x_v, sd[p + ".vert_stack.weight"], sd[p + ".vert_stack.bias"], kernel // 2, 1)
+    h_vert = h_vert[:, :, :x_v.shape[-2], :]
+    out_v = gated_activation(h_vert + h[:, :, None, None])
+    h_horiz = conv2d(x_h, sd[p + ".horiz_stack.weight"], sd[p + ".horiz_stack.bias"], 0, 1)
+    h_horiz = h_horiz[:, :, :, :x_h.shape[-1]]
+    v2h = conv2d(h_vert, sd[p + ".vert_to_horiz.weight"], sd[p + ".vert_to_horiz.bias"], 0, 0)
+    out = gated_activation(v2h + h_horiz + h[:, :, None, None])
+    out_h = conv2d(out, sd[p + ".horiz_resid.weight"], sd[p + ".horiz_resid.bias"], 0, 0)
+    if residual:
+        out_h = out_h + x_h
+    return out_v, out_h
+
+
+def pixelcnn_forward(x, label, aud, sd, n_layers):
+    """GatedPixelCNN.forward (`gated_pixelcnn_v2.py:130-150`), audio=True, bh_model=True, eval mode.
+
+    x (B,H,2) int64 codes, label (B,) int64, aud (B,256,H,2) -> logits (B,input_dim,H,2).
+    `sd` must already have gone through `causal_weights`.
+    """
+    e = sd["embedding.weight"][x]                                           # (B,H,W,C)
+    xv = xh = np.ascontiguousarray(e.transpose(0, 3, 1, 2))
+    for i in range(n_layers):
+        if i == 1:
+            a = conv2d(aud, sd["embedding_aud.weight"], sd["embedding_aud.bias"], 0, 0)
+            xv = conv2d(np.concatenate([xv, a], 1), sd["fusion_v.weight"], sd["fusion_v.bias"], 0, 0)
+            xh = conv2d(np.concatenate([xh, a], 1), sd["fusion_h.weight"], sd["fusion_h.bias"], 0, 0)
+        xv, xh = gated_masked_conv2d(xv, xh, label, sd, f"layers.{i}", 7 if i == 0 else 3, i != 0)
+    y = relu(conv2d(xh, sd["output_conv.0.weight"], sd["output_conv.0.bias"], 0, 0))
+    return conv2d(y, sd["output_conv.2.weight"], sd["output_conv.2.bias"], 0, 0)
+
+
+def softmax(x):
+    m = x.max(axis=-1, keepdims=True)
+    e = np.exp(x - m)
+    return (e / e.sum(axis=-1, keepdims=True)).astype(F32)
+
+
+def pixelcnn_generate(label, aud, sd, n_layers, H, uniforms=None, return_logits=False):
+    """GatedPixelCNN.generate (`gated_pixelcnn_v2.py:152-177`) — the O(H^2) full-grid recompute, as written.
+
+    `uniforms is None`: greedy harness of SURVEY.md §0.3 (argmax of logits[:, :, i, j], ties -> lowest
+    index).  Otherwise `uniforms` (B,H,2) in [0,1) drives an inverse-CDF draw from
+    softmax(logits[:, :, i, j]) — the distribution `probs.multinomial(1)` samples (`:173-176`); torch's
+    RNG stream itself is not reproducible off-torch, so stochastic parity is defined on injected uniforms.
+    """
+    sd = causal_weights(sd, n_layers)
+    B = aud.shape[0]
+    x = np.zeros((B, H, 2), np.int64)
+    logs = []
+    for i in range(H):
+        for j in range(2):
+            lg = pixelcnn_forward(x, label, aud, sd, n_layers)[:, :, i, j]
+            if return_logits:
+                logs.append(lg.copy())
+            if uniforms is None:
+                x[:, i, j] = np.argmax(lg, axis=-1)
+            else:
+                x[:, i, j] = sample_inverse_cdf(lg, uniforms[:, i, j])
+    if return_logits:
+        return x, np.stack(logs, 1).reshape(B, H, 2, -1)
+    return x
+
+
+def sample_inverse_cdf(logits, u):
+    """Draw from softmax(logits) with a given uniform: smallest k with cumsum(p)[k] > u * sum(p)."""
+    m = logits.max(axis=-1, keepdims=True)
+    e = np.exp((logits - m).astype(F32)).astype(F32)
+    c = np.cumsum(e, axis=-1, dtype=F32)
+    thr = (u.astype(F32) * c[:, -1])[:, None]
+    k = (c <= thr).sum(axis=-1)
+    return np.minimum(k, logits.shape[-1] - 1).astype(np.int64)
+
+
+# ----------------------------------------------------------------------------------------------
+# nets/smplx_body_pixel.py / nets/smplx_body_vq.py orchestration
+# ----------------------------------------------------------------------------------------------
+
+def body_pixel_infer(mfcc, ids, sd_audio, sd_pix, sd_body, sd_hand, n_layers=15, uniforms=None):
+    """`TrainWrapper.infer_on_audio` after the MFCC front-end (`smplx_body_pixel.py:272-285`).
+
+    mfcc (B,T,64) -> (codes (B,H,2) int64, poses (B,4H,129) float32); greedy unless `uniforms`.
+    """
+    feat = audio_encoder(np.ascontiguousarray(mfcc.transpose(0, 2, 1)), sd_audio)          # (B,256,H)
+    aud = np.repeat(feat[:, :, :, None], 2, axis=3)
+    H = aud.shape[2]
+    codes = pixelcnn_generate(ids, aud, sd_pix, n_layers, H, uniforms)
+    body = vqvae_decode(codes[..., 0], sd_body)
+    hand = vqvae_decode(codes[..., 1], sd_hand)
+    poses = np.concatenate([body, hand], axis=1).transpose(0, 2, 1)
+    return codes, np.ascontiguousarray(poses), feat
+
+
+def body_vq_infer(poses129, sd_body, sd_hand):
+    """`s2g_body_vq.TrainWrapper.infer_on_audio(initial_pose=gt)` core (`smplx_body_vq.py:254-281,293`).
+
+    poses129 (B,T,129) in c_index order -> (out (T, B*129), codes (B,H,2)).
+    """
+    _, rb, ib = vqvae_forward(poses129[..., :39], sd_body)
+    _, rh, ih = vqvae_forward(poses129[..., 39:], sd_hand)
+    pred = np.concatenate([rb, rh], axis=1).transpose(0, 2, 1)                  # (B,T,129)
+    out = np.concatenate(list(pred), axis=1)                                     # np.concatenate(output, axis=1)
+    return out, np.stack([ib, ih], -1)

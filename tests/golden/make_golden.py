@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own modules.
+
+Runs only in the build container, where /root/reference exists (it does not on the GPU box):
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference (`/root/reference`, pure PyTorch) is imported through the shim of SURVEY.md
+Appendix C (third-party modules that are absent here and unused on the hot path are stubbed;
+nothing is written to the reference tree).  Weights are the seeded synthetic checkpoints of
+`talkshow_amd/synth.py`, loaded with `strict=True`, so the key names / shapes those builders
+emit are checked against the reference here.  Inputs are seeded too; inputs AND outputs are
+stored so the CPU oracle (`oracle/`) and the HIP path can both be compared on identical data.
+
+Greedy decode: the reference has none (`gated_pixelcnn_v2.py:173-176` always samples), so — as
+SURVEY.md §0.3 prescribes — the harness below drives the reference `GatedPixelCNN.forward`
+position by position and takes `torch.argmax(logits[:, :, i, j], -1)`.
+"""
+import argparse
+import contextlib
+import importlib.machinery
+import io
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    import torch  # noqa: F401
+    import transformers  # noqa: F401  (must precede the stubs)
+    from transformers import Wav2Vec2Config, Wav2Vec2Processor  # noqa: F401
+
+    def stub(name):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    for n in ["torchvision", "torchvision.datasets", "torchvision.transforms", "torchaudio",
+              "torchaudio.functional", "torchaudio.transforms", "torchaudio.sox_effects", "librosa",
+              "python_speech_features", "textgrid", "smplx"]:
+        stub(n)
+    sys.modules["torchaudio.sox_effects"].apply_effects_tensor = None
+    os.chdir(REF)
+    # the repo root also holds a package called `nets` (our drop-in); the reference's must win here
+    sys.path = [p for p in sys.path if os.path.abspath(p or ".") != REPO]
+    sys.path.insert(0, REF)
+    import nets
+    assert nets.__file__.startswith(REF), nets.__file__
+    from nets.spg import wav2vec as w2
+    w2.Wav2Vec2Model.from_pretrained = classmethod(
+        lambda cls, *a, **k: cls(Wav2Vec2Config(attn_implementation="eager")))
+    return nets
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def greedy_reference(pix, label, aud, H):
+    """Greedy harness around the reference forward; returns codes and per-step logits."""
+    import torch
+    B = aud.shape[0]
+    x = torch.zeros((B, H, 2), dtype=torch.int64)
+    step_logits = torch.zeros((B, H, 2, pix.embedding.weight.shape[0]))
+    with torch.no_grad():
+        for i in range(H):
+            for j in range(2):
+                logits = pix(x, label, aud)
+                step_logits[:, i, j] = logits[:, :, i, j]
+                x[:, i, j] = torch.argmax(logits[:, :, i, j], dim=-1)
+    return x, step_logits
+
+
+def margins(step_logits):
+    top2 = np.sort(step_logits.reshape(-1, step_logits.shape[-1]), axis=-1)[:, -2:]
+    return top2[:, 1] - top2[:, 0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+
+    sys.path.insert(0, REPO)
+    from talkshow_amd import synth
+    sys.path.remove(REPO)
+    nets = import_reference()
+    import torch
+    from nets.spg.gated_pixelcnn_v2 import GatedPixelCNN
+    from nets.spg.vqvae_1d import VQVAE, AudioEncoder
+
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    T = synth.to_torch
+    meta = {"torch": torch.__version__, "numpy": np.__version__, "cases": {}}
+
+    def save(name, **arrs):
+        if args.only and args.only != name:
+            return
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+        meta["cases"][name] = {k: list(np.asarray(v).shape) for k, v in arrs.items()}
+        print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+    def want(name):
+        return not args.only or args.only == name
+
+    # ---- 1. VQ-VAE, small and full architecture: encode -> argmin -> gather -> decode -----------
+    for name, kw, B, Tn in [
+        ("vq_small", dict(in_dim=39, num_embeddings=128, num_hiddens=128), 3, 24),
+        ("vq_full_body", dict(in_dim=39, num_embeddings=2048, num_hiddens=1024), 2, 40),
+        ("vq_full_hand", dict(in_dim=90, num_embeddings=2048, num_hiddens=1024, salt=1), 2, 40),
+    ]:
+        if not want(name):
+            continue
+        sd = synth.vqvae_state_dict(seed=7, **kw)
+        net = VQVAE(kw["in_dim"], 64, kw["num_embeddings"], kw["num_hiddens"], 2, 512)
+        net.load_state_dict(T(sd), strict=True)
+        net.eval()
+        poses = synth.gt_poses(11, B, Tn, dim=kw["in_dim"])
+        with torch.no_grad():
+            z = net.encoder(torch.from_numpy(poses).transpose(1, 2))        # (B,64,H)
+            e, idx = net.vq_layer(z)                                        # eval branch
+            e2, recon = net(gt_poses=torch.from_numpy(poses))               # VQVAE.forward eval
+            dec, _ = net.decode(b=B, w=idx.shape[1], latents=idx)
+        assert torch.equal(e, e2) and torch.equal(dec, recon)
+        print(name, "z std", float(z.std()), "recon std", float(recon.std()), "uniq codes", idx.unique().numel())
+        save(name, poses=poses, z=z.numpy(), idx=idx.numpy(), quantized=e.numpy(), recon=recon.numpy(),
+             cfg=np.asarray([kw["in_dim"], 64, kw["num_embeddings"], kw["num_hiddens"], 2, kw.get("salt", 0), 7]))
+
+    # ---- 2. audio encoder ------------------------------------------------------------------------
+    if want("audioenc_full"):
+        sd = synth.audioencoder_state_dict(seed=7)
+        net = AudioEncoder(64, 256, 2, 256)
+        net.load_state_dict(T(sd), strict=True)
+        net.eval()
+        mf = synth.mfcc_features(12, 2, 60)
+        with torch.no_grad():
+            out = net(torch.from_numpy(mf).transpose(1, 2))
+        print("audioenc out std", float(out.std()))
+        save("audioenc_full", mfcc=mf, out=out.numpy())
+
+    # ---- 3. PixelCNN greedy, small and full architecture -----------------------------------------
+    for name, kw, B, H in [
+        ("pix_small", dict(input_dim=128, dim=64, n_layers=4), 3, 10),
+        ("pix_full", dict(input_dim=2048, dim=256, n_layers=15), 2, 12),
+    ]:
+        if not want(name):
+            continue
+        sd = synth.pixelcnn_state_dict(seed=7, **kw)
+        pix = quiet(GatedPixelCNN, kw["input_dim"], kw["dim"], kw["n_layers"], 4, True, True)
+        pix.load_state_dict(T(sd), strict=True)
+        pix.eval()
+        rng = np.random.default_rng(13)
+        aud = rng.standard_normal((B, H, 256)).astype(np.float32)           # (B,H,256) row features
+        label = synth.speaker_ids(B)
+        aud_t = torch.from_numpy(aud).permute(0, 2, 1).unsqueeze(-1).repeat(1, 1, 1, 2)
+        codes, step_logits = greedy_reference(pix, torch.from_numpy(label), aud_t, H)
+        with torch.no_grad():
+            full_logits = pix(codes, torch.from_numpy(label), aud_t)        # teacher-forced full grid
+        m = margins(step_logits.numpy())
+        print(name, "logit std", float(step_logits.std()), "margin min/median", float(m.min()), float(np.median(m)),
+              "uniq", codes.unique().numel())
+        save(name, aud=aud, label=label, codes=codes.numpy(), step_logits=step_logits.numpy().astype(np.float32),
+             full_logits=full_logits.permute(0, 2, 3, 1).numpy(), margin=m,
+             cfg=np.asarray([kw["input_dim"], kw["dim"], kw["n_layers"], 4, 7]))
+
+    # ---- 4. end-to-end through the reference WRAPPERS (ckpt plumbing included) --------------------
+    if want("body_e2e_full") or want("body_vq_e2e_full"):
+        tmp = tempfile.mkdtemp(prefix="ts_golden_")
+        vq_path = os.path.join(tmp, "vq.pth")
+        body_sd = synth.vqvae_state_dict(seed=7, in_dim=39)
+        hand_sd = synth.vqvae_state_dict(seed=7, in_dim=90, salt=1)
+        torch.save({"generator": {"g_body": T(body_sd), "g_hand": T(hand_sd)}}, vq_path)
+        cfg = json.load(open(os.path.join(REF, "config/body_pixel.json")))
+        cfg["Model"]["vq_path"] = vq_path
+        from trainer.config import Object
+        config = Object(cfg)
+        targs = argparse.Namespace(gpu="cpu", infer=True)
+
+        if want("body_e2e_full"):
+            B, Tn = 2, 300
+            w = quiet(nets.s2g_body_pixel, targs, config)
+            ckpt = {"generator": T(synth.pixelcnn_state_dict(seed=7)),
+                    "audioencoder": T(synth.audioencoder_state_dict(seed=7))}
+            # exactly what scripts/demo.py:58-59 does with ckpt['generator']
+            w.load_state_dict({"generator": {("module." + k): v for k, v in ckpt["generator"].items()},
+                               "audioencoder": ckpt["audioencoder"]})
+            mf = synth.mfcc_features(21, B, Tn)
+            ids = synth.speaker_ids(B)
+            w.generator.eval(); w.g_body.eval(); w.g_hand.eval(); w.audioencoder.eval()
+            with torch.no_grad():
+                feat = w.audioencoder(torch.from_numpy(mf).transpose(1, 2), frame_num=0)   # (B,256,H)
+                aud = feat.unsqueeze(-1).repeat(1, 1, 1, 2)
+                H = aud.shape[2]
+                codes, step_logits = greedy_reference(w.generator, torch.from_numpy(ids), aud, H)
+                body, _ = w.g_body.decode(b=B, w=H, latents=codes[..., 0])
+                hand, _ = w.g_hand.decode(b=B, w=H, latents=codes[..., 1])
+                poses = torch.cat([body, hand], dim=1).transpose(1, 2)
+            m = margins(step_logits.numpy())
+            print("body_e2e_full: H", H, "margin min/median", float(m.min()), float(np.median(m)),
+                  "pose std", float(poses.std()), "uniq codes", codes.unique().numel())
+            save("body_e2e_full", mfcc=mf, ids=ids, aud_feat=feat.permute(0, 2, 1).numpy(), codes=codes.numpy(),
+                 poses=poses.numpy(), margin=m)
+
+        if want("body_vq_e2e_full"):
+            B, Tn = 2, 300
+            vcfg = json.load(open(os.path.join(REF, "config/body_vq.json")))
+            vconfig = Object(vcfg)
+            w = quiet(nets.s2g_body_vq, targs, vconfig)
+            w.load_state_dict({"g_body": T(body_sd), "g_hand": T(hand_sd)})
+            from data_utils.lower_body import c_index_3d
+            full = np.zeros((B, 165, Tn), np.float32)
+            p129 = synth.gt_poses(22, B, Tn)
+            full[:, c_index_3d, :] = p129.transpose(0, 2, 1)
+            out = quiet(w.infer_on_audio, torch.zeros(B, 64, Tn), initial_pose=torch.from_numpy(full),
+                        id=torch.tensor([0]), fps=30)
+            with torch.no_grad():
+                _, lat_b = w.g_body.encode(gt_poses=torch.from_numpy(p129[..., :39]))
+                _, lat_h = w.g_hand.encode(gt_poses=torch.from_numpy(p129[..., 39:]))
+            print("body_vq_e2e_full: out", out.shape, "std", float(out.std()))
+            save("body_vq_e2e_full", poses129=p129, out=out, codes=np.stack([lat_b.numpy(), lat_h.numpy()], -1),
+                 c_index=np.asarray(c_index_3d))
+
+    meta_path = os.path.join(HERE, "golden_meta.json")
+    old = json.load(open(meta_path)) if os.path.exists(meta_path) else {"cases": {}}
+    old["cases"].update(meta["cases"])
+    old.update({k: v for k, v in meta.items() if k != "cases"})
+    json.dump(old, open(meta_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""Pin the CPU oracle (oracle/talkshow_oracle.py) to the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import talkshow_oracle as O
+from talkshow_amd import synth
+
+TOL = 2e-5   # oracle (numpy BLAS) vs reference (torch/oneDNN): summation-order noise only
+
+
+def _vq_sd(cfg):
+    in_dim, emb, n_emb, hid, layers, salt, seed = [int(v) for v in cfg]
+    return synth.vqvae_state_dict(seed=seed, in_dim=in_dim, embedding_dim=emb, num_embeddings=n_emb,
+                                  num_hiddens=hid, num_residual_layers=layers, salt=salt)
+
+
+@pytest.mark.parametrize("name", ["vq_small", "vq_full_body", "vq_full_hand"])
+def test_vqvae_encode_decode(golden, name):
+    g = golden(name)
+    sd = _vq_sd(g["cfg"])
+    z, e, idx = O.vqvae_encode(g["poses"], sd)
+    np.testing.assert_allclose(z, g["z"], atol=TOL, rtol=0)
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(e, g["quantized"])
+    recon = O.vqvae_decode(idx, sd)
+    np.testing.assert_allclose(recon, g["recon"], atol=TOL, rtol=0)
+    e2, recon2, _ = O.vqvae_forward(g["poses"], sd)
+    np.testing.assert_array_equal(recon2, recon)
+
+
+def test_audio_encoder(golden):
+    g = golden("audioenc_full")
+    out = O.audio_encoder(np.ascontiguousarray(g["mfcc"].transpose(0, 2, 1)), synth.audioencoder_state_dict(seed=7))
+    np.testing.assert_allclose(out, g["out"], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["pix_small", "pix_full"])
+def test_pixelcnn_greedy(golden, name):
+    g = golden(name)
+    input_dim, dim, n_layers, n_cls, seed = [int(v) for v in g["cfg"]]
+    sd = synth.pixelcnn_state_dict(seed=seed, input_dim=input_dim, dim=dim, n_layers=n_layers, n_classes=n_cls)
+    aud = np.repeat(g["aud"].transpose(0, 2, 1)[:, :, :, None], 2, axis=3)
+    H = g["codes"].shape[1]
+    # teacher-forced full grid first (no error propagation), then the free-running greedy loop
+    full = O.pixelcnn_forward(g["codes"], g["label"], aud, O.causal_weights(sd, n_layers), n_layers)
+    np.testing.assert_allclose(full.transpose(0, 2, 3, 1), g["full_logits"], atol=2e-4, rtol=0)
+    if name == "pix_small":
+        codes, logits = O.pixelcnn_generate(g["label"], aud, sd, n_layers, H, return_logits=True)
+        np.testing.assert_allclose(logits, g["step_logits"], atol=2e-4, rtol=0)
+    else:
+        codes = O.pixelcnn_generate(g["label"], aud, sd, n_layers, H)
+    np.testing.assert_array_equal(codes, g["codes"])
+
+
+def test_causality(golden):
+    """Receptive-field property: logits at (i, j) do not depend on codes at or after (i, j)."""
+    g = golden("pix_small")
+    input_dim, dim, n_layers, n_cls, seed = [int(v) for v in g["cfg"]]
+    sd = O.causal_weights(synth.pixelcnn_state_dict(seed=seed, input_dim=input_dim, dim=dim, n_layers=n_layers), n_layers)
+    aud = np.repeat(g["aud"].transpose(0, 2, 1)[:, :, :, None], 2, axis=3)
+    x = g["codes"].copy()
+    base = O.pixelcnn_forward(x, g["label"], aud, sd, n_layers)
+    i, j = 4, 1
+    x2 = x.copy()
+    x2[:, i, j:] = (x2[:, i, j:] + 5) % input_dim
+    x2[:, i + 1:] = (x2[:, i + 1:] + 9) % input_dim
+    pert = O.pixelcnn_forward(x2, g["label"], aud, sd, n_layers)
+    np.testing.assert_array_equal(base[:, :, :i], pert[:, :, :i])
+    np.testing.assert_array_equal(base[:, :, i, :j + 1], pert[:, :, i, :j + 1])
+    assert np.abs(base[:, :, i + 1] - pert[:, :, i + 1]).max() > 1e-3
+
+
+def test_sampler_distribution():
+    rng = np.random.default_rng(0)
+    logits = rng.standard_normal((1, 16)).astype(np.float32) * 2
+    p = O.softmax(logits)[0]
+    n = 20000
+    draws = O.sample_inverse_cdf(np.repeat(logits, n, 0), rng.random(n))
+    freq = np.bincount(draws, minlength=16) / n
+    chi2 = (n * (freq - p) ** 2 / p).sum()
+    assert chi2 < 45.0     # 15 dof, p ~ 1e-4
+
+
+@pytest.mark.slow
+def test_body_e2e_full(golden):
+    g = golden("body_e2e_full")
+    codes, poses, feat = O.body_pixel_infer(
+        g["mfcc"], g["ids"], synth.audioencoder_state_dict(seed=7), synth.pixelcnn_state_dict(seed=7),
+        synth.vqvae_state_dict(seed=7, in_dim=39), synth.vqvae_state_dict(seed=7, in_dim=90, salt=1))
+    np.testing.assert_allclose(feat.transpose(0, 2, 1), g["aud_feat"], atol=TOL, rtol=0)
+    np.testing.assert_array_equal(codes, g["codes"])
+    np.testing.assert_allclose(poses, g["poses"], atol=1e-4, rtol=0)
+
+
+def test_body_vq_e2e_full(golden):
+    g = golden("body_vq_e2e_full")
+    out, codes = O.body_vq_infer(g["poses129"], synth.vqvae_state_dict(seed=7, in_dim=39),
+                                 synth.vqvae_state_dict(seed=7, in_dim=90, salt=1))
+    np.testing.assert_array_equal(codes, g["codes"])
+    np.testing.assert_allclose(out, g["out"], atol=1e-4, rtol=0)
