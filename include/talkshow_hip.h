@@ -1,0 +1,153 @@
+/*
+ * talkshow_hip.h — C ABI of the MI355X-native speech -> SMPL-X body-motion inference path.
+ *
+ * The reference (yhw-yhw/TalkSHOW) has no FFI: its boundary for this path is the Python surface of
+ * package `nets`.  This header is what a host language binds underneath that surface;
+ * our own `nets/` package (same names / signatures as the reference's) is the first client, through
+ * ctypes (talkshow_amd/_lib.py).  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; ts_last_error() gives the message
+ *     (thread-local).  Nothing throws, nothing aborts.
+ *   - "dev" pointers are HIP device pointers on the context's device; "host" pointers are CPU memory.
+ *   - all activations are fp32, time-major / channel-last ("NLC"): x[b][t][c]; code indices are int64
+ *     exactly as the reference's torch.int64 latents.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Calls enqueue work
+ *     and return; the caller synchronises (torch.cuda.synchronize() / hipStreamSynchronize).
+ *   - weights are handed over ONCE as the reference's own state_dict (name, host pointer, shape); BatchNorm
+ *     folding, mask-A zeroing, tap/segment packing and upload happen inside the library.
+ */
+#ifndef TALKSHOW_HIP_H
+#define TALKSHOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ts_ctx ts_ctx;
+typedef struct ts_convnet ts_convnet;     /* AudioEncoder            nets/spg/vqvae_1d.py:11-34          */
+typedef struct ts_vqvae ts_vqvae;         /* VQVAE                   nets/spg/vqvae_1d.py:152-208        */
+typedef struct ts_pixelcnn ts_pixelcnn;   /* GatedPixelCNN           nets/spg/gated_pixelcnn_v2.py:90-177 */
+
+/* One entry of a reference state_dict: key name as the reference spells it (an optional "module." prefix is
+ * accepted and stripped, nets/smplx_body_pixel.py:119-126), fp32 host data, shape.  int64 buffers
+ * (num_batches_tracked) may be passed with data == NULL; they are ignored. */
+typedef struct ts_tensor {
+    const char *name;
+    const float *data;
+    int32_t ndim;
+    int64_t shape[4];
+} ts_tensor;
+
+/* ---- context ------------------------------------------------------------------------------------------ */
+int ts_ctx_create(int device, ts_ctx **out);
+void ts_ctx_destroy(ts_ctx *ctx);
+const char *ts_last_error(void);
+/* library / build identification, e.g. "talkshow_hip 0.1 gfx950" */
+const char *ts_version(void);
+
+/* ---- AudioEncoder(in_dim=64, num_hiddens, num_residual_layers, ·)  — vqvae_1d.py:11-34 ------------------ */
+int ts_audioenc_create(ts_ctx *ctx, const ts_tensor *sd, int n, int in_dim, int num_hiddens,
+                       int num_residual_layers, ts_convnet **out);
+void ts_convnet_destroy(ts_convnet *net);
+/* AudioEncoder.forward (vqvae_1d.py:27-34): mfcc_dev (B,T,in_dim) -> feat_dev (B,H,num_hiddens), H = T//4
+ * (two k4/s2/p1 convolutions: L -> floor(L/2)). */
+int ts_audioenc_forward(ts_convnet *net, const float *mfcc_dev, int B, int T, float *feat_dev, void *stream);
+
+/* ---- VQVAE(in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers, ·) — vqvae_1d.py:152 -- */
+int ts_vqvae_create(ts_ctx *ctx, const ts_tensor *sd, int n, int in_dim, int embedding_dim, int num_embeddings,
+                    int num_hiddens, int num_residual_layers, ts_vqvae **out);
+void ts_vqvae_destroy(ts_vqvae *vq);
+/* VQVAE.encode (vqvae_1d.py:196-199) + VectorQuantizerEMA eval branch (vqvae_modules.py:274-286,311-323):
+ * poses_dev (B,T,in_dim) -> z_dev (B,H,embedding_dim) [may be NULL], latents_dev (B,H) int64,
+ * quantized_dev (B,H,embedding_dim) [may be NULL]. */
+int ts_vqvae_encode(ts_vqvae *vq, const float *poses_dev, int B, int T, float *z_dev, int64_t *latents_dev,
+                    float *quantized_dev, void *stream);
+/* VQVAE.decode(latents=...) (vqvae_1d.py:201-208): latents_dev (B,H) int64 -> recon written into
+ * out_dev[b][t][out_col0 + c], c < in_dim, row stride out_ld floats (so body and hand decoders can write
+ * the two halves of one (B,4H,129) buffer — the torch.cat of smplx_body_pixel.py:285). */
+int ts_vqvae_decode(ts_vqvae *vq, const int64_t *latents_dev, int B, int H, float *out_dev, int out_ld,
+                    int out_col0, void *stream);
+/* VQVAE.forward, eval branch (vqvae_1d.py:184-189): encode -> quantise -> decode in one call. */
+int ts_vqvae_forward(ts_vqvae *vq, const float *poses_dev, int B, int T, int64_t *latents_dev, float *out_dev,
+                     int out_ld, int out_col0, void *stream);
+
+/* ---- GatedPixelCNN(input_dim, dim, n_layers, n_classes, audio=True, bh_model=True) ---------------------- */
+int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd, int n, int input_dim, int dim, int n_layers,
+                       int n_classes, int aud_dim, ts_pixelcnn **out);
+void ts_pixelcnn_destroy(ts_pixelcnn *pix);
+
+#define TS_SAMPLE_GREEDY 0      /* argmax(logits), ties -> lowest index (the harness of SURVEY.md §0.3)           */
+#define TS_SAMPLE_UNIFORMS 1    /* inverse-CDF draw from softmax(logits) with caller-supplied uniforms (B,H,2)    */
+#define TS_SAMPLE_PHILOX 2      /* same draw, uniforms from Philox4x32-10(seed; clip index, position)             */
+#define TS_TEACHER_FORCED 3     /* do not sample: positions are read from codes_dev (GatedPixelCNN.forward)       */
+
+/* GatedPixelCNN.generate (gated_pixelcnn_v2.py:152-177), computed incrementally (row cache) instead of the
+ * reference's full-grid recompute per position; same arithmetic per position.
+ *   label_dev (B,) int64 speaker class; aud_dev (B,H,aud_dim) per-row audio features (the reference's
+ *   (B,aud_dim,H,2) tensor is this repeated over the 2 columns, smplx_body_pixel.py:274);
+ *   codes_dev (B,H,2) int64: output (input when mode == TS_TEACHER_FORCED);
+ *   uniforms_dev (B,H,2) fp32 for TS_SAMPLE_UNIFORMS else NULL; seed / clip_index0 for TS_SAMPLE_PHILOX
+ *   (clip b draws from subsequence clip_index0 + b, so results do not depend on how clips are sharded);
+ *   logits_dev optional (B,H,2,input_dim) fp32: logits of every position as the reference's forward gives them.
+ *   pre_codes_dev / pre_aud_dev / H0: optional continuity prefix (gated_pixelcnn_v2.py:158-165): H0 rows of
+ *   already generated codes (B,H0,2) and their audio features (B,H0,aud_dim); pass NULL, NULL, 0 otherwise. */
+int ts_pixelcnn_generate(ts_pixelcnn *pix, const int64_t *label_dev, const float *aud_dev, int B, int H, int mode,
+                         const float *uniforms_dev, uint64_t seed, int64_t clip_index0, int64_t *codes_dev,
+                         float *logits_dev, const int64_t *pre_codes_dev, const float *pre_aud_dev, int H0,
+                         void *stream);
+
+/* ---- whole wrappers --------------------------------------------------------------------------------------- */
+/* s2g_body_pixel.TrainWrapper.infer_on_audio after the MFCC front-end (smplx_body_pixel.py:272-285):
+ * mfcc_dev (B,T,64), ids_dev (B,) int64 -> codes_dev (B,H,2) int64, poses_dev (B,4H,body_dim+hand_dim). */
+int ts_body_pixel_infer(ts_convnet *audioenc, ts_pixelcnn *pix, ts_vqvae *vq_body, ts_vqvae *vq_hand,
+                        const float *mfcc_dev, const int64_t *ids_dev, int B, int T, int mode,
+                        const float *uniforms_dev, uint64_t seed, int64_t clip_index0, int64_t *codes_dev,
+                        float *poses_dev, void *stream);
+/* s2g_body_vq.TrainWrapper.infer_on_audio(initial_pose=gt) core (smplx_body_vq.py:254-281):
+ * poses_dev (B,T,body_dim+hand_dim) in c_index order -> recon_dev same shape, codes_dev (B,H,2) int64. */
+int ts_body_vq_infer(ts_vqvae *vq_body, ts_vqvae *vq_hand, const float *poses_dev, int B, int T,
+                     int64_t *codes_dev, float *recon_dev, void *stream);
+
+/* ---- single operators (kernel-level parity tests call these; weights given in the reference's layouts) ------ */
+/* nn.Conv1d / nn.ConvTranspose1d (+ optional fused activation: 0 none, 1 LeakyReLU(0.2), 2 ReLU) on NLC data:
+ * x_dev (B,Lin,Cin); w_host (Cout,Cin,K) or, transposed, (Cin,Cout,K); bias_host (Cout) or NULL;
+ * out_dev (B,Lout,Cout).  Supported: K in {1,3} stride 1 pad (K-1)/2; K=4 stride 2 pad 1 (both directions). */
+int ts_op_conv1d(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_host,
+                 const float *bias_host, int Cout, int K, int stride, int pad, int transposed, int act,
+                 float *out_dev, void *stream);
+/* VectorQuantizerEMA.get_code_indices (vqvae_modules.py:311-319): x_dev (M,dim), codebook_dev (ncode,dim)
+ * -> idx_dev (M) int64 = argmin_j (|x|^2 + |e_j|^2 - 2 x.e_j), ties -> lowest j. */
+int ts_op_vq_argmin(ts_ctx *ctx, const float *x_dev, int M, const float *codebook_dev, int ncode, int dim,
+                    int64_t *idx_dev, void *stream);
+/* F.linear on few rows (the per-position GEMM of the PixelCNN chain): x_dev (M,K), w_host (N,K), bias_host (N)
+ * -> out_dev (M,N); relu optional. */
+int ts_op_linear(ts_ctx *ctx, const float *x_dev, int M, int K, const float *w_host, const float *bias_host,
+                 int N, int relu, float *out_dev, void *stream);
+/* the per-position sampler: logits_dev (B,V) -> idx_dev (B) int64; mode TS_SAMPLE_GREEDY or
+ * TS_SAMPLE_UNIFORMS (uniforms_dev (B)). */
+int ts_op_sample(ts_ctx *ctx, const float *logits_dev, int B, int V, int mode, const float *uniforms_dev,
+                 int64_t *idx_dev, void *stream);
+
+/* Tuning / roofline entry (not part of the drop-in surface): a stride-1 conv layer (K = 1 or 3, Cin % 32 == 0)
+ * whose weights are ALREADY packed on the device as [round128(Cout)][K*Cin] (tap-major, k contiguous), launched
+ * `iters` times between two HIP events recorded on `stream`; tile: 0 = production heuristic, 1 = 128x128,
+ * 2 = 64x64, 3 = 128x64, 4 = 64x128.  *ms_out = mean launch duration in milliseconds. */
+int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
+                       const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
+                       void *stream);
+
+/* ---- instrumentation ---------------------------------------------------------------------------------------- */
+/* Per-kernel-family device time of the calls made on this context since the last reset, measured with HIP
+ * events on the launch stream when enabled (adds synchronisation: benchmarking / profiling only).
+ * families: 0 conv_gemm, 1 skinny_gemm (PixelCNN chain), 2 vq / sampling / glue.  ms_out[3], launches_out[3],
+ * flops_out[3] (algorithmic 2*M*N*K of the GEMM launches; 0 for family 2). */
+int ts_prof_enable(ts_ctx *ctx, int on);
+int ts_prof_read(ts_ctx *ctx, double *ms_out, int64_t *launches_out, double *flops_out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TALKSHOW_HIP_H */

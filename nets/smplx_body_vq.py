@@ -1,0 +1,121 @@
+"""Drop-in for `nets/smplx_body_vq.py` of the reference (VQ-VAE encode -> quantise -> decode of GT poses)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from nets.base import TrainWrapperBaseClass, resolve_device
+from nets.utils import denormalize
+from talkshow_amd import _lib
+from talkshow_amd.modules import VQVAE as s2g_body
+from talkshow_amd.pose_index import c_index_3d
+
+
+class TrainWrapper(TrainWrapperBaseClass):
+    def __init__(self, args, config):
+        self.args = args
+        self.config = config
+        self.device = resolve_device(self.args.gpu)
+        self.global_step = 0
+
+        self.convert_to_6d = self.config.Data.pose.convert_to_6d
+        self.expression = self.config.Data.pose.expression
+        self.epoch = 0
+        self.init_params()
+        self.num_classes = 4
+        self.composition = self.config.Model.composition
+        if self.composition:
+            self.g_body = s2g_body(self.each_dim[1], embedding_dim=64, num_embeddings=config.Model.code_num,
+                                   num_hiddens=1024, num_residual_layers=2, num_residual_hiddens=512).to(self.device)
+            self.g_hand = s2g_body(self.each_dim[2], embedding_dim=64, num_embeddings=config.Model.code_num,
+                                   num_hiddens=1024, num_residual_layers=2, num_residual_hiddens=512).to(self.device)
+        else:
+            self.g = s2g_body(self.each_dim[1] + self.each_dim[2], embedding_dim=64, num_embeddings=config.Model.code_num,
+                              num_hiddens=1024, num_residual_layers=2, num_residual_hiddens=512).to(self.device)
+        self.discriminator = None
+        if self.convert_to_6d:
+            raise NotImplementedError("convert_to_6d=true is not used by any shipped config (SURVEY.md §2)")
+        self.c_index = c_index_3d
+        super().__init__(args, config)
+
+    def init_optimizer(self):
+        self.g_body_optimizer = self.g_hand_optimizer = self.g_optimizer = None
+        self.generator_optimizer = self.discriminator_optimizer = None
+
+    def state_dict(self):
+        if self.composition:
+            return {'g_body': self.g_body.state_dict(), 'g_body_optim': None,
+                    'g_hand': self.g_hand.state_dict(), 'g_hand_optim': None,
+                    'discriminator': None, 'discriminator_optim': None}
+        return {'g': self.g.state_dict(), 'g_optim': None, 'discriminator': None, 'discriminator_optim': None}
+
+    def load_state_dict(self, state_dict):
+        if self.composition:
+            self.g_body.load_state_dict(state_dict['g_body'])
+            self.g_hand.load_state_dict(state_dict['g_hand'])
+        else:
+            self.g.load_state_dict(state_dict['g'])
+
+    def parameters(self):
+        return self.g_body.parameters() if self.composition else self.g.parameters()
+
+    def reconstruct_batch(self, poses129):
+        """Batched device entry: poses (B,T,129) in c_index order -> (codes (B,H,2), recon (B,T',129))."""
+        dev = self.g_body._dev()
+        poses129 = torch.as_tensor(poses129, dtype=torch.float32, device=dev).contiguous()
+        B, T, _ = poses129.shape
+        H = T // 2 // 2
+        codes = torch.empty((B, H, 2), dtype=torch.int64, device=dev)
+        recon = torch.empty((B, 4 * H, poses129.shape[-1]), dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().ts_body_vq_infer(self.g_body.handle(), self.g_hand.handle(), _lib.dptr(poses129), B, T,
+                                                _lib.dptr(codes), _lib.dptr(recon), _lib.stream_ptr()))
+        return codes, recon
+
+    def infer_on_audio(self, aud_fn, initial_pose=None, norm_stats=None, exp=None, var=None, w_pre=False,
+                       continuity=False, id=None, fps=15, sr=22000, smooth=False, **kwargs):
+        '''
+        initial_pose: (B, C, T)  -> reconstruction, np.concatenate'd over the batch: (T, B*129)
+        [smplx_body_vq.py:208-295]
+        '''
+        assert self.args.infer, "train mode"
+        if self.config.Data.pose.normalization:
+            assert norm_stats is not None
+            data_mean = norm_stats[0]
+            data_std = norm_stats[1]
+
+        # the reference dereferences gt unconditionally (smplx_body_vq.py:255); say so instead of a TypeError
+        if initial_pose is None:
+            raise ValueError("s2g_body_vq.infer_on_audio needs initial_pose=(B,165,T): it reconstructs given poses")
+        gt = initial_pose[:, :, :].to(self.device).to(torch.float32)
+        if id is None:
+            id = F.one_hot(torch.tensor([[0]]), self.num_classes).to(self.device)
+
+        with torch.no_grad():
+            gt_poses = gt[:, self.c_index].permute(0, 2, 1).contiguous()          # (B, T, 129)
+            if self.composition:
+                if continuity:
+                    chunks = []
+                    for i in range(5):                                            # smplx_body_vq.py:258-268
+                        _, r = self.reconstruct_batch(gt_poses[:, i * 60:(i + 1) * 60])
+                        chunks.append(r)
+                    pred_poses = torch.cat(chunks, dim=1)
+                else:
+                    _, pred_poses = self.reconstruct_batch(gt_poses)
+            else:
+                _, pred_poses = self.g.forward_nlc(gt_poses)
+            pred_poses = pred_poses.cpu().numpy()                                  # already (B, T, C)
+        output = pred_poses
+
+        if self.config.Data.pose.normalization:
+            output = denormalize(output, data_mean, data_std)
+
+        if smooth:
+            lamda = 0.8
+            smooth_f = 10
+            frame = 149
+            for i in range(smooth_f):
+                f = frame + i
+                l = lamda * (i + 1) / smooth_f
+                output[0, f] = (1 - l) * output[0, f - 1] + l * output[0, f]
+
+        output = np.concatenate(output, axis=1)
+        return output

@@ -279,14 +279,68 @@ def pixelcnn_generate(label, aud, sd, n_layers, H, uniforms=None, return_logits=
     return x
 
 
-def sample_inverse_cdf(logits, u):
-    """Draw from softmax(logits) with a given uniform: smallest k with cumsum(p)[k] > u * sum(p)."""
-    m = logits.max(axis=-1, keepdims=True)
-    e = np.exp((logits - m).astype(F32)).astype(F32)
-    c = np.cumsum(e, axis=-1, dtype=F32)
-    thr = (u.astype(F32) * c[:, -1])[:, None]
-    k = (c <= thr).sum(axis=-1)
-    return np.minimum(k, logits.shape[-1] - 1).astype(np.int64)
+def sample_inverse_cdf(logits, u, nthreads=256):
+    """Draw from softmax(logits) with a given uniform: first index whose running sum of exp(l - max) exceeds u * total.
+
+    The reference draws with `probs.multinomial(1)` (`gated_pixelcnn_v2.py:173-176`); any exact inverse-CDF draw has that
+    distribution.  The summation STRUCTURE below is the one the HIP sampler uses (so draws compare bit for bit):
+    `nthreads` contiguous chunks summed left to right, chunk sums prefix-summed left to right, then a left-to-right walk
+    inside the owning chunk; all in float32.
+    """
+    B, V = logits.shape
+    chunk = (V + nthreads - 1) // nthreads
+    out = np.zeros(B, np.int64)
+    for b in range(B):
+        m = logits[b].max()
+        e = np.exp((logits[b] - m).astype(F32)).astype(F32)
+        pre = np.zeros(nthreads + 1, F32)
+        c = F32(0)
+        for t in range(nthreads):
+            s_ = F32(0)
+            for v in range(t * chunk, min((t + 1) * chunk, V)):
+                s_ = F32(s_ + e[v])
+            c = F32(c + s_)
+            pre[t + 1] = c
+        thr = F32(F32(u[b]) * c)
+        owner = None
+        for t in range(nthreads):
+            if pre[t] <= thr and (thr < pre[t + 1] or t == nthreads - 1):
+                owner = t
+                break
+        v0, v1 = owner * chunk, min((owner + 1) * chunk, V)
+        if v0 >= V:
+            out[b] = V - 1
+            continue
+        k, c = v1 - 1, pre[owner]
+        for v in range(v0, v1):
+            c = F32(c + e[v])
+            if c > thr:
+                k = v
+                break
+        out[b] = k
+    return out
+
+
+def philox_uniform(seed, clip_index, position):
+    """Philox4x32-10, counter (position, clip_lo, clip_hi, 0), key (seed_lo, seed_hi); u = (word0 >> 8) * 2^-24."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c = [position & 0xFFFFFFFF, clip_index & 0xFFFFFFFF, (clip_index >> 32) & 0xFFFFFFFF, 0]
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return np.float32((c[0] >> 8) * (1.0 / 16777216.0))
+
+
+def philox_uniforms(seed, clip_index0, B, H):
+    """(B,H,2) uniforms the HIP sampler draws in TS_SAMPLE_PHILOX mode: clip b -> subsequence clip_index0 + b."""
+    u = np.zeros((B, H, 2), F32)
+    for b in range(B):
+        for r in range(H):
+            for j in range(2):
+                u[b, r, j] = philox_uniform(seed, clip_index0 + b, r * 2 + j)
+    return u
 
 
 # ----------------------------------------------------------------------------------------------

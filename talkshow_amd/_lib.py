@@ -1,0 +1,135 @@
+"""ctypes binding of libtalkshow_hip.so (C ABI: include/talkshow_hip.h).
+
+There is NO fallback: if the library has not been built, or no gfx950 device is present when a context is
+requested, this module raises.  PyTorch is imported first on purpose — the library must share the HIP runtime
+instance that owns the torch tensors whose device pointers it is handed.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch  # noqa: F401  (loads libamdhip64 before ours)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtalkshow_hip.so")
+
+TS_SAMPLE_GREEDY, TS_SAMPLE_UNIFORMS, TS_SAMPLE_PHILOX, TS_TEACHER_FORCED = 0, 1, 2, 3
+
+
+class TsTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+_vp, _i, _i64, _u64, _fp = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); every symbol include/talkshow_hip.h declares
+SIGNATURES = {
+    "ts_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "ts_ctx_destroy": (None, [_vp]),
+    "ts_last_error": (C.c_char_p, []),
+    "ts_version": (C.c_char_p, []),
+    "ts_audioenc_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ts_convnet_destroy": (None, [_vp]),
+    "ts_audioenc_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ts_vqvae_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ts_vqvae_destroy": (None, [_vp]),
+    "ts_vqvae_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "ts_vqvae_decode": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "ts_vqvae_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "ts_pixelcnn_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ts_pixelcnn_destroy": (None, [_vp]),
+    "ts_pixelcnn_generate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ts_body_pixel_infer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _u64, _i64, _vp, _vp, _vp]),
+    "ts_body_vq_infer": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "ts_op_conv1d": (_i, [_vp, _vp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ts_op_conv1d_timed": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
+    "ts_op_vq_argmin": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "ts_op_linear": (_i, [_vp, _vp, _i, _i, _fp, _fp, _i, _i, _vp, _vp]),
+    "ts_op_sample": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ts_prof_enable": (_i, [_vp, _i]),
+    "ts_prof_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _i]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and declare every prototype.  Raises if it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libtalkshow_hip: " + load().ts_last_error().decode())
+
+
+def fptr(a):
+    """host float32 numpy array -> POINTER(c_float) (the array must outlive the call)."""
+    return a.ctypes.data_as(_fp) if a is not None else None
+
+
+def dptr(t):
+    """torch CUDA tensor -> raw device pointer (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device tensors handed to the C ABI must be contiguous HIP tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pack_state_dict(sd):
+    """{name: tensor/ndarray} -> (ts_tensor array, n, keepalive).  Non-float entries are passed with data=NULL."""
+    items = list(sd.items())
+    arr = (TsTensor * len(items))()
+    keep = []
+    for k, (name, v) in enumerate(items):
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        v = np.asarray(v)
+        bname = name.encode()
+        keep.append(bname)
+        arr[k].name = bname
+        arr[k].ndim = min(v.ndim, 4)
+        for d in range(min(v.ndim, 4)):
+            arr[k].shape[d] = v.shape[d]
+        if v.dtype == np.float32 and v.ndim <= 4:
+            v = np.ascontiguousarray(v)
+            keep.append(v)
+            arr[k].data = fptr(v)
+        else:
+            arr[k].data = None
+    return arr, len(items), keep
+
+
+_contexts = {}
+
+
+def context(device_index=None):
+    """One ts_ctx per HIP device per process."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("talkshow_amd needs a HIP device (MI355X / gfx950); torch.cuda.is_available() is False. "
+                           "There is no CPU path.")
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if device_index not in _contexts:
+        lib = load()
+        h = _vp()
+        check(lib.ts_ctx_create(int(device_index), C.byref(h)))
+        _contexts[device_index] = h
+    return _contexts[device_index]

@@ -1,0 +1,193 @@
+// Whole-wrapper entry points and the single-operator entry points used by the kernel-level parity tests.
+#include "host_common.h"
+
+using namespace ts;
+
+namespace {
+struct BodyWork {
+    DevBuf feat;
+    DevBuf lat[2];
+};
+// scratch between the stages of ts_body_pixel_infer: audio feature map, split latents
+BodyWork &body_work() {
+    static thread_local BodyWork w;
+    return w;
+}
+}  // namespace
+
+extern "C" {
+
+// s2g_body_pixel.TrainWrapper.infer_on_audio, device part (nets/smplx_body_pixel.py:272-285)
+int ts_body_pixel_infer(ts_convnet *ae, ts_pixelcnn *pix, ts_vqvae *vb, ts_vqvae *vh, const float *mfcc,
+                        const int64_t *ids, int B, int T, int mode, const float *uniforms, uint64_t seed, int64_t clip0,
+                        int64_t *codes, float *poses, void *stream) {
+    if (!ae || !pix || !vb || !vh || !mfcc || !ids || !codes || !poses) return fail("ts_body_pixel_infer: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = (T / 2) / 2;
+    if (H < 1) return fail("ts_body_pixel_infer: clip too short");
+    const int aud_dim = convnet_hidden(ae), body_dim = vqvae_in_dim(vb), hand_dim = vqvae_in_dim(vh);
+    BodyWork &w = body_work();
+    TS_TRY(w.feat.ensure((size_t)B * H * aud_dim * sizeof(float)));
+    TS_TRY(ts_audioenc_forward(ae, mfcc, B, T, w.feat.f(), s));
+    TS_TRY(ts_pixelcnn_generate(pix, ids, w.feat.f(), B, H, mode, uniforms, seed, clip0, codes, nullptr, nullptr, nullptr,
+                                0, s));
+    // body_latents = latents[..., 0]; hand_latents = latents[..., 1]  (:279-280)
+    for (int k = 0; k < 2; ++k) {
+        TS_TRY(w.lat[k].ensure((size_t)B * H * sizeof(int64_t)));
+        TS_HIP(hipMemcpy2DAsync(w.lat[k].p, sizeof(int64_t), codes + k, 2 * sizeof(int64_t), sizeof(int64_t),
+                                (size_t)B * H, hipMemcpyDeviceToDevice, s));
+    }
+    const int ld = body_dim + hand_dim;
+    TS_TRY(ts_vqvae_decode(vb, static_cast<int64_t *>(w.lat[0].p), B, H, poses, ld, 0, s));
+    TS_TRY(ts_vqvae_decode(vh, static_cast<int64_t *>(w.lat[1].p), B, H, poses, ld, body_dim, s));
+    return 0;
+}
+
+int ts_op_conv1d(ts_ctx *ctx, const float *x, int B, int Lin, int Cin, const float *w, const float *bias, int Cout,
+                 int K, int stride, int pad, int transposed, int act, float *out, void *stream) {
+    if (!ctx || !x || !w || !out) return fail("ts_op_conv1d: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int kind;
+    if (!transposed && stride == 1 && (K == 1 || K == 3) && pad == (K - 1) / 2) kind = 0;
+    else if (!transposed && stride == 2 && K == 4 && pad == 1) kind = 1;
+    else if (transposed && stride == 2 && K == 4 && pad == 1) kind = 2;
+    else return fail("ts_op_conv1d: unsupported geometry");
+    std::vector<float> zb(Cout, 0.f);
+    ts_tensor t[2];
+    t[0].name = "op.weight";
+    t[0].data = w;
+    t[0].ndim = 3;
+    t[0].shape[0] = transposed ? Cin : Cout;
+    t[0].shape[1] = transposed ? Cout : Cin;
+    t[0].shape[2] = K;
+    t[1].name = "op.bias";
+    t[1].data = bias ? bias : zb.data();
+    t[1].ndim = 1;
+    t[1].shape[0] = Cout;
+    StateDict sd(t, 2);
+    ConvLayer L;
+    TS_TRY(pack_conv_layer(sd, "op", "", "", kind, K, Cin, Cout, act, &L));
+    DevBuf xin;
+    const float *xp = x;
+    int ldx = Cin;
+    if (Cin % 32 != 0) {
+        TS_TRY(xin.ensure((size_t)B * Lin * L.cin_pad * sizeof(float)));
+        TS_HIP(launch_pad_rows(x, Cin, Cin, xin.f(), L.cin_pad, L.cin_pad, (long)B * Lin, s));
+        xp = xin.f();
+        ldx = L.cin_pad;
+    }
+    ConvParams p;
+    conv_layer_params(L, xp, ldx, B, Lin, nullptr, 0, out, Cout, 0, Cout, &p);
+    TS_TRY(run_conv(ctx, p, 0, s));
+    TS_HIP(hipStreamSynchronize(s));   // temporaries die with this frame
+    return 0;
+}
+
+// Tuning / roofline entry (not part of the drop-in surface): a stride-1 conv layer (K = 1 or 3, Cin % 32 == 0) with
+// weights ALREADY packed on the device as [round128(Cout)][K*Cin] (tap-major), launched `iters` times between two HIP
+// events on `stream` with a chosen tile shape (0 = the heuristic used in production).  ms_out = mean launch duration.
+int ts_op_conv1d_timed(ts_ctx *ctx, const float *x, int B, int Lin, int Cin, const float *w_packed_dev,
+                       const float *bias_dev, int Cout, int K, int tile, int iters, float *out, float *ms_out,
+                       void *stream) {
+    if (!ctx || !x || !w_packed_dev || !out) return fail("ts_op_conv1d_timed: null argument");
+    if (Cin % 32 || (K != 1 && K != 3)) return fail("ts_op_conv1d_timed: unsupported geometry");
+    hipStream_t s = (hipStream_t)stream;
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.M = B * Lin;
+    p.Lout = p.Lin = Lin;
+    p.stride = 1;
+    p.ldx = Cin;
+    p.ldo = Cout;
+    p.N = Cout;
+    p.Ktot = K * Cin;
+    p.act = 1;
+    p.ngroups = 1;
+    p.g[0].x = x;
+    p.g[0].w = w_packed_dev;
+    p.g[0].bias = bias_dev;
+    p.g[0].out = out;
+    p.g[0].nseg = K;
+    for (int k = 0; k < K; ++k) p.g[0].seg[k] = ConvSeg{K == 1 ? 0 : k - 1, 0, Cin};
+    hipEvent_t a, b;
+    TS_HIP(hipEventCreate(&a));
+    TS_HIP(hipEventCreate(&b));
+    TS_HIP(launch_conv_gemm(p, tile, s));   // warm-up
+    TS_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) TS_HIP(launch_conv_gemm(p, tile, s));
+    TS_HIP(hipEventRecord(b, s));
+    TS_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    TS_HIP(hipEventElapsedTime(&ms, a, b));
+    if (ms_out) *ms_out = ms / (iters > 0 ? iters : 1);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return 0;
+}
+
+int ts_op_vq_argmin(ts_ctx *ctx, const float *x, int M, const float *cb, int ncode, int dim, int64_t *idx, void *stream) {
+    if (!ctx || !x || !cb || !idx) return fail("ts_op_vq_argmin: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf sq;
+    TS_TRY(sq.ensure((size_t)ncode * sizeof(float)));
+    TS_HIP(launch_row_sqnorm(cb, ncode, dim, sq.f(), s));
+    TS_HIP(launch_vq_argmin(x, dim, M, cb, sq.f(), ncode, dim, idx, 1, s));
+    TS_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ts_op_linear(ts_ctx *ctx, const float *x, int M, int K, const float *w, const float *bias, int N, int relu,
+                 float *out, void *stream) {
+    if (!ctx || !x || !w || !out) return fail("ts_op_linear: null argument");
+    if (K % 8 != 0) return fail("ts_op_linear: K must be a multiple of 8");
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf wd, bd;
+    TS_TRY(wd.upload(w, (size_t)N * K * sizeof(float)));
+    if (bias) TS_TRY(bd.upload(bias, (size_t)N * sizeof(float)));
+    SkinnyParams q;
+    std::memset(&q, 0, sizeof(q));
+    q.M = M;
+    q.N = N;
+    q.nseg = 1;
+    q.Ktot = K;
+    q.seg[0].base = x;
+    q.seg[0].row_stride = K;
+    q.seg[0].len = K;
+    q.W = wd.f();
+    q.ldw = K;
+    q.bias = bias ? bd.f() : nullptr;
+    q.epi = EPI_LINEAR;
+    q.relu = relu;
+    q.out = out;
+    q.out_stride = N;
+    TS_TRY(run_skinny(ctx, q, s));
+    TS_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ts_op_sample(ts_ctx *ctx, const float *logits, int B, int V, int mode, const float *uniforms, int64_t *idx,
+                 void *stream) {
+    if (!ctx || !logits || !idx) return fail("ts_op_sample: null argument");
+    if (mode != TS_SAMPLE_GREEDY && mode != TS_SAMPLE_UNIFORMS) return fail("ts_op_sample: bad mode");
+    if (mode == TS_SAMPLE_UNIFORMS && !uniforms) return fail("ts_op_sample: uniforms required");
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf tok;
+    TS_TRY(tok.ensure((size_t)B * sizeof(int)));
+    SampleParams sp;
+    std::memset(&sp, 0, sizeof(sp));
+    sp.logits = logits;
+    sp.B = B;
+    sp.V = V;
+    sp.mode = mode;
+    sp.uniforms = uniforms;
+    sp.u_stride = 1;
+    sp.tok32 = tok.i();
+    sp.tok_stride = 1;
+    sp.codes = idx;
+    sp.code_stride = 1;
+    TS_HIP(launch_sample(sp, s));
+    TS_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // extern "C"

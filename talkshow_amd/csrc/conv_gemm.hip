@@ -1,0 +1,184 @@
+// conv_gemm_f32 — implicit-GEMM 1-D convolution on the gfx950 fp32 matrix cores.
+//
+// Replaces, for the whole conv stacks of the body path, the PyTorch ops
+//   nn.Conv1d k3/s1/p1, k4/s2/p1, k1 ; nn.ConvTranspose1d k4/s2/p1 ; BatchNorm1d(eval) ; LeakyReLU(0.2) ; ReLU ;
+//   the `h + x` of Res_CNR_Stack            (reference: nets/spg/vqvae_modules.py:87-212, nets/spg/vqvae_1d.py)
+// BatchNorm (and the parallel residual convolution of the down/up layers) is folded into the packed weights on the
+// host (models.cpp), so one launch = one reference layer incl. its activation and residual add.
+//
+// Mapping to CDNA4:
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (an fmaf chain per output), 64 cycles / instruction / SIMD = 157 TFLOP/s
+//     chip peak — the roof this kernel is measured against.
+//   * a workgroup (256 threads = 4 waves, one per SIMD) owns a BM x BN output tile; K advances in chunks of 32
+//     floats staged through LDS.  LDS rows are 36 floats wide: a wave's ds_read_b128 (one row per lane, 16 B) then
+//     touches 16 distinct 4-bank slots per lane group -> conflict free.
+//   * each lane fetches 4 consecutive k with one ds_read_b128 and feeds them to 4 consecutive MFMAs; the two lane
+//     halves take k {0..3} and {4..7} of every group of 8 — a permutation of the K order applied identically to A
+//     and B, so the product is unchanged and LDS traffic is 1 b128 per 4 MFMA per operand tile.
+//   * global -> register -> LDS double buffering: the next chunk's 16-byte coalesced loads are in flight while the
+//     current chunk's MFMAs issue; one barrier per chunk.
+//   * convolution taps / stride / transposed-conv phases are "segments": (row shift, channel range) pairs, so only
+//     valid taps are multiplied (no zero-insertion for ConvTranspose, no wasted taps for stride 2).
+#include "kernels.h"
+
+namespace ts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;   // 36 floats = 144 B row pitch
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int PA = BM / 32, PB = BN / 32;   // 32-row load passes per operand
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_LD];
+
+    const ConvGroup &g = p.g[blockIdx.z];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // ---- per-thread global-load geometry: row (tid/8) of each 32-row pass, float4 column (tid%8) ----
+    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+    long a_rowbase[PA];   // (b*Lin) input row base, or -1 if the output row is out of range
+    int a_t[PA];          // t*stride
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        int m = m0 + i * 32 + lrow;
+        if (m < p.M) {
+            int b = m / p.Lout, t = m - b * p.Lout;
+            a_rowbase[i] = (long)b * p.Lin;
+            a_t[i] = t * p.stride;
+        } else {
+            a_rowbase[i] = -1;
+            a_t[i] = 0;
+        }
+    }
+    const float *wbase = g.w + (long)(n0 + lrow) * p.Ktot + lc4;
+
+    f32x4 ra[PA], rb[PB];
+    auto load_chunk = [&](int s, int cc, int kofs) {
+        const int d = g.seg[s].d;
+        const int coff = g.seg[s].c0 + cc * BK + lc4;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int it = a_t[i] + d;
+            if (a_rowbase[i] >= 0 && it >= 0 && it < p.Lin)
+                ra[i] = *reinterpret_cast<const f32x4 *>(g.x + (a_rowbase[i] + it) * p.ldx + coff);
+            else
+                ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            rb[i] = *reinterpret_cast<const f32x4 *>(wbase + (long)i * 32 * p.Ktot + kofs);
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4 *>(&As[buf][i * 32 + lrow][lc4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4 *>(&Bs[buf][i * 32 + lrow][lc4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- K loop over (segment, 32-channel chunk), software pipelined ----
+    int s = 0, cc = 0, kofs = 0;
+    load_chunk(s, cc, kofs);
+    store_chunk(0);
+    __syncthreads();
+    int buf = 0;
+    const int nchunks = p.Ktot / BK;
+    for (int it = 0; it < nchunks; ++it) {
+        // advance to the next chunk and start its loads
+        bool has_next = it + 1 < nchunks;
+        if (has_next) {
+            kofs += BK;
+            if (++cc * BK >= g.seg[s].len) { cc = 0; ++s; }
+            load_chunk(s, cc, kofs);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const f32x4 *>(&As[buf][wm * WM + i * 32 + li][q * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][wn * WN + j * 32 + li][q * 8 + lh * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (has_next) store_chunk(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue: bias (+ residual) + activation, masked store ----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + li;
+        const float bv = g.bias ? g.bias[n] : 0.f;
+        const bool nok = n < p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (nok && m < p.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (g.res) v += g.res[(long)m * p.ldr + n];
+                    if (p.act == 1) v = v >= 0.f ? v : v * 0.2f;
+                    else if (p.act == 2) v = v > 0.f ? v : 0.f;
+                    g.out[(long)m * p.ldo + g.out_col0 + n] = v;
+                }
+            }
+        }
+    }
+}
+
+double conv_gemm_flops(const ConvParams &p) { return 2.0 * p.M * (double)p.N * p.Ktot * p.ngroups; }
+
+static int pick_tile(const ConvParams &p) {
+    // Prefer the large tile when it alone fills the chip; otherwise smaller tiles so that the tile count is
+    // >> 256 CUs and the hardware dispatcher can balance the tail (MI355X_MICROARCH: 256 CUs, 8 XCDs).
+    auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ngroups; };
+    if (tiles(128, 128) >= 2 * 256) return 1;
+    if (p.N <= 64 || tiles(128, 64) < 256) return 2;
+    return tiles(128, 64) >= 2 * 256 ? 3 : 2;
+}
+
+hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream) {
+    if (tile == 0) tile = pick_tile(p);
+    dim3 block(256);
+    auto grid = [&](int bm, int bn) { return dim3((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, p.ngroups); };
+    switch (tile) {
+        case 1: hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 64, 64>), grid(128, 128), block, 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32>), grid(64, 64), block, 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((conv_gemm_kernel<128, 64, 64, 32>), grid(128, 64), block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((conv_gemm_kernel<64, 128, 32, 64>), grid(64, 128), block, 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ts

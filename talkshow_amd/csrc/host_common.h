@@ -1,0 +1,174 @@
+// Host-side helpers shared by models.cpp / pixelcnn.cpp / api.cpp: error channel, device buffers, the
+// reference-state_dict view, the launch wrappers that feed the per-family profiler.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/talkshow_hip.h"
+#include "kernels.h"
+
+namespace ts {
+
+void set_error(const std::string &m);
+inline int fail(const std::string &m) {
+    set_error(m);
+    return 1;
+}
+
+#define TS_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess) return ::ts::fail(std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+#define TS_TRY(expr)              \
+    do {                          \
+        int r__ = (expr);         \
+        if (r__ != 0) return r__; \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int ensure(size_t n) {   // grow-only; contents are NOT preserved
+        if (n <= bytes) return 0;
+        release();
+        TS_HIP(hipMalloc(&p, n));
+        bytes = n;
+        return 0;
+    }
+    int upload(const void *host, size_t n) {
+        TS_TRY(ensure(n));
+        TS_HIP(hipMemcpy(p, host, n, hipMemcpyHostToDevice));
+        return 0;
+    }
+    float *f() const { return static_cast<float *>(p); }
+    int *i() const { return static_cast<int *>(p); }
+};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// view of a reference state_dict, "module." prefixes stripped (nets/smplx_body_pixel.py:119-126)
+struct StateDict {
+    std::map<std::string, const ts_tensor *> m;
+    StateDict(const ts_tensor *t, int n) {
+        for (int i = 0; i < n; ++i) {
+            std::string k = t[i].name ? t[i].name : "";
+            size_t pos;
+            while ((pos = k.find("module.")) != std::string::npos) k.erase(pos, 7);
+            m[k] = &t[i];
+        }
+    }
+    // returns nullptr (and sets the error) if missing or shape mismatch
+    const float *get(const std::string &key, std::initializer_list<int64_t> shape) const {
+        auto it = m.find(key);
+        if (it == m.end() || !it->second->data) {
+            set_error("state_dict: missing key '" + key + "'");
+            return nullptr;
+        }
+        const ts_tensor *t = it->second;
+        bool ok = t->ndim == (int)shape.size();
+        int i = 0;
+        for (int64_t s : shape) {
+            if (ok && t->shape[i] != s) ok = false;
+            ++i;
+        }
+        if (!ok) {
+            std::string got = "(", want = "(";
+            for (int j = 0; j < t->ndim; ++j) got += std::to_string(t->shape[j]) + ",";
+            for (int64_t s : shape) want += std::to_string(s) + ",";
+            set_error("state_dict: shape mismatch for '" + key + "': got " + got + ") want " + want + ")");
+            return nullptr;
+        }
+        return t->data;
+    }
+};
+
+// ---- per-family device-time profiler (ts_prof_*) ------------------------------------------------------------
+enum { FAM_CONV = 0, FAM_SKINNY = 1, FAM_MISC = 2, FAM_COUNT = 3 };
+
+struct Profiler {
+    bool on = false;
+    struct Rec {
+        hipEvent_t a, b;
+        int fam;
+    };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double ms[FAM_COUNT] = {0, 0, 0};
+    double flops[FAM_COUNT] = {0, 0, 0};
+    long launches[FAM_COUNT] = {0, 0, 0};
+    hipEvent_t get_event();
+    void begin(int fam, hipStream_t s);
+    void end(hipStream_t s);
+    int collect();   // synchronises the recorded events and folds them into ms[]
+    void reset();
+    ~Profiler();
+};
+
+}  // namespace ts
+
+struct ts_ctx {
+    int device = 0;
+    ts::Profiler prof;
+    ts::DevBuf neg1;   // a single int32 -1 (gather index meaning "zero row")
+};
+
+namespace ts {
+
+int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s);
+int run_skinny(ts_ctx *ctx, const SkinnyParams &p, hipStream_t s);
+// misc launches are wrapped with this scope guard so they show up under FAM_MISC
+struct MiscScope {
+    ts_ctx *ctx;
+    hipStream_t s;
+    MiscScope(ts_ctx *c, hipStream_t st) : ctx(c), s(st) {
+        if (ctx->prof.on) ctx->prof.begin(FAM_MISC, s);
+    }
+    ~MiscScope() {
+        if (ctx->prof.on) ctx->prof.end(s);
+    }
+};
+
+// ---- a folded + packed convolution layer -------------------------------------------------------------------
+struct ConvLayer {
+    int kind = 0;   // 0: stride-1 (k1 / k3), 1: down (k4 s2 p1), 2: up (ConvTranspose k4 s2 p1)
+    int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, npad = 0, ktot = 0;
+    int act = 0;
+    int ngroups = 1, nseg = 0;
+    ConvSeg segs[2][4];
+    DevBuf w, bias;   // [ngroups][npad][ktot], [ngroups][npad]
+    std::string name;
+};
+
+// Packs one reference layer: conv `conv_key` (+ BatchNorm `norm_key` folded, + parallel residual conv
+// `res_key` folded) into `out`.  kind as above; k = kernel size for kind 0 (1 or 3).
+int pack_conv_layer(const StateDict &sd, const std::string &conv_key, const std::string &norm_key,
+                    const std::string &res_key, int kind, int k, int cin, int cout, int act, ConvLayer *out);
+// generic: pack an (N,K) row-major matrix (+bias) as a k1 ConvLayer (used for the PixelCNN audio precompute)
+int pack_linear_layer(const float *w, long ldw, const float *bias, int N, int K, ConvLayer *out);
+
+// Fills ConvParams for `layer` applied to x (B, Lin, ldx) -> out; returns Lout (rows per clip of the output buffer).
+// For kind 2 the output buffer has 2*Lin rows of cout_pad (or ldo) floats.
+int conv_layer_params(const ConvLayer &layer, const float *x, int ldx, int B, int Lin, const float *res, int ldr,
+                      float *out, int ldo, int out_col0, int n_store, ConvParams *p);
+
+// accessors so that api.cpp needs no knowledge of the model structs
+int convnet_hidden(const ts_convnet *n);
+int vqvae_in_dim(const ts_vqvae *v);
+
+}  // namespace ts

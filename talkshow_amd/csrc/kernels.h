@@ -1,0 +1,126 @@
+// Internal kernel-launch interface shared by the .hip kernel files and the host-side model code.
+// Everything here is plain structs + launch functions; the public C ABI is include/talkshow_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ts {
+
+// ------------------------------------------------------------------------------------------------
+// conv_gemm_f32: 1-D convolution / transposed convolution / pointwise linear as an implicit GEMM on the
+// fp32 MFMA (v_mfma_f32_32x32x2_f32).  Activations are NLC ([b][t][c], row stride ld floats, c padded to
+// a multiple of 32 with zeros).  One output row m = b*Lout + t gathers, per segment s, `len` channels
+// starting at c0 of input row t*stride + d (zero if outside [0, Lin)); the packed weight row n holds the
+// segments back to back (Ktot floats, K-contiguous), BatchNorm already folded in.
+// ------------------------------------------------------------------------------------------------
+struct ConvSeg {
+    int d;    // input row shift
+    int c0;   // first input channel
+    int len;  // channels in this segment (multiple of 32)
+};
+
+struct ConvGroup {
+    const float *x;     // input  [B*Lin][ldx]
+    const float *w;     // packed weights [Npad][Ktot]
+    const float *bias;  // [Npad]
+    const float *res;   // optional residual [M][ldr] added before the activation
+    float *out;         // output [M][ldo], written at columns out_col0 .. out_col0+N-1
+    int out_col0;
+    int nseg;
+    ConvSeg seg[4];
+};
+
+struct ConvParams {
+    int M, Lout, Lin, stride;
+    int ldx, ldo, ldr;
+    int N;     // columns stored per group (weights/bias are padded to a multiple of 128 rows)
+    int Ktot;
+    int act;   // 0 none, 1 LeakyReLU(0.2), 2 ReLU
+    int ngroups;
+    ConvGroup g[4];
+};
+
+// tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128 (for tuning / tests)
+hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream);
+double conv_gemm_flops(const ConvParams &p);
+
+// ------------------------------------------------------------------------------------------------
+// skinny_gemm_f32: out[M x N] = A[M x K] * W[N x K]^T with M = a few tens of rows (the batch of clips at one
+// code position).  The A operand is a concatenation of up to 6 segments, each either a dense row-major
+// block or rows gathered from a table through an int32 index (token -> embedding row).  Each workgroup owns
+// 32 output columns and splits K over its waves; epilogues fuse bias, an additive term, the per-class
+// conditioning and the tanh*sigmoid gate.
+// ------------------------------------------------------------------------------------------------
+struct SkinnySeg {
+    const float *base;   // dense: row m at base + (m >> row_shift) * row_stride (+ col offset baked in base)
+    const int *gidx;     // gather: row = base + gidx[m * gidx_stride] * row_stride ; negative index -> zero row
+    long row_stride;
+    long gidx_stride;
+    int row_shift;
+    int len;             // multiple of 8
+};
+
+enum { EPI_LINEAR = 0, EPI_GATE = 1 };
+
+struct SkinnyParams {
+    int M, N;            // N = number of weight rows (EPI_GATE: 2*gateD per group)
+    int nseg, Ktot;
+    SkinnySeg seg[6];
+    const float *W;      // weight row n at W + n*ldw (K-contiguous, Ktot floats used)
+    long ldw;
+    const float *bias;   // [N] or null
+    const float *add1;   // optional: add1[(m >> add1_shift) * add1_stride + n]
+    long add1_stride;
+    int add1_shift;
+    const float *add2;   // optional second additive term, same indexing scheme
+    long add2_stride;
+    int add2_shift;
+    const float *cls;    // optional class conditioning table [n_classes][cls_ld]; added as cls[label[m]*cls_ld + (n % cls_ld)]
+    const int *label;
+    int cls_ld;
+    int epi;             // EPI_LINEAR / EPI_GATE
+    int relu;            // EPI_LINEAR only
+    int gateD;           // EPI_GATE: channels per gate half (columns n and n+gateD pair up inside each 2*gateD group)
+    float *out;          // EPI_LINEAR: [M][out_stride] N columns; EPI_GATE: [M][out_stride], N/2 columns
+    long out_stride;
+    float *pre;          // EPI_GATE optional: pre-activation (acc + bias + add1, without cls) [M][pre_stride]
+    long pre_stride;
+};
+
+hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// VQ / sampling / glue kernels
+// ------------------------------------------------------------------------------------------------
+// idx[m] = argmin_j (|x_m|^2 + |e_j|^2) - 2 x_m.e_j   (ties -> lowest j); also writes int32 copy if idx32 != null
+hipError_t launch_vq_argmin(const float *x, int ldx, int M, const float *codebook, const float *code_sq, int ncode,
+                            int dim, int64_t *idx, long idx_stride, hipStream_t stream);
+// code_sq[j] = sum_c e[j][c]^2
+hipError_t launch_row_sqnorm(const float *e, int n, int dim, float *out, hipStream_t stream);
+// out[m][0..width) = table[idx[m*idx_stride]][0..width)
+hipError_t launch_gather_rows(const float *table, int ld_table, const int64_t *idx, long idx_stride, int M, int width,
+                              float *out, int ldo, hipStream_t stream);
+// dst[m][0..cpad) = src[m][0..c) then zeros
+hipError_t launch_pad_rows(const float *src, int lds, int c, float *dst, int ldd, int cpad, long M, hipStream_t stream);
+// int64 -> int32 (labels, teacher-forced codes)
+hipError_t launch_i64_to_i32(const int64_t *src, int *dst, long n, hipStream_t stream);
+
+struct SampleParams {
+    const float *logits;   // [B][V]
+    int B, V;
+    int mode;              // TS_SAMPLE_* ; TEACHER_FORCED copies
+    const float *uniforms; // element for clip b at uniforms[b * u_stride]
+    long u_stride;
+    uint64_t seed;
+    int64_t clip_index0;
+    uint32_t position;     // Philox counter word: linear position (row*2 + col)
+    int *tok32;            // token for clip b written to tok32[b * tok_stride]
+    long tok_stride;
+    int64_t *codes;        // same position in the int64 output, codes[b * code_stride]
+    long code_stride;
+    float *logits_copy;    // optional: logits_copy[b * copy_stride + v] = logits[b][v]
+    long copy_stride;
+};
+hipError_t launch_sample(const SampleParams &p, hipStream_t stream);
+
+}  // namespace ts

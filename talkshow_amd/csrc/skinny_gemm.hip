@@ -1,0 +1,152 @@
+// skinny_gemm_f32 — the per-position GEMM of the autoregressive PixelCNN chain.
+//
+// One launch = one dependent stage of GatedMaskedConv2d / the logits head evaluated at ONE code position for the
+// whole batch of clips (reference: nets/spg/gated_pixelcnn_v2.py:61-87,120-124,137-144): M = B (or 2B) rows,
+// N = 256..2048 output channels, K = 256..1536.  The chain is latency bound (≈5k dependent stages per batch), so
+// the kernel is built to be SHORT rather than to stream: a workgroup owns 32 output columns for all rows, its
+// W (4/8/16) waves split K, every wave issues all of its 16-byte operand loads up front (operands go straight
+// from L2 to VGPRs — a weight row is read by exactly one lane, LDS staging would only add a round trip), runs its
+// share of v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains), and the partial 32x32 tiles are summed through LDS in
+// a fixed order (deterministic).  Epilogues fuse bias, an additive term (v->h contribution / residual / audio
+// term), the class conditioning and the tanh*sigmoid gate: the tile's columns are 16 "tanh" channels followed by
+// their 16 "sigmoid" partners, so the gate is one cross-lane exchange (lane ^ 16).
+#include "kernels.h"
+
+namespace ts {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int W>
+__global__ __launch_bounds__(W * 64) void skinny_gemm_kernel(const SkinnyParams p) {
+    __shared__ float red[W][16][64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int tile = blockIdx.x, mt = blockIdx.y;
+
+    // output column of this lane
+    int n;
+    if (p.epi == EPI_GATE) {
+        const int tiles_per_group = p.gateD >> 4;
+        const int group = tile / tiles_per_group, ch0 = (tile - group * tiles_per_group) << 4;
+        n = group * 2 * p.gateD + (li >> 4) * p.gateD + ch0 + (li & 15);
+    } else {
+        n = tile * 32 + li;
+    }
+    const bool n_ok = n < p.N;
+    const float *wrow = p.W + (long)(n_ok ? n : 0) * p.ldw + lh * 4;
+
+    // A row of this lane
+    const int m = mt * 32 + li;
+    const bool m_ok = m < p.M;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int Q = p.Ktot >> 3;
+    const int qbeg = (Q * wave) / W, qend = (Q * (wave + 1)) / W;
+    int qs = 0;
+    for (int s = 0; s < p.nseg; ++s) {
+        const SkinnySeg &sg = p.seg[s];
+        const int qlen = sg.len >> 3;
+        const int lo = qbeg > qs ? qbeg : qs;
+        const int hi = qend < qs + qlen ? qend : qs + qlen;
+        if (lo < hi) {
+            const float *arow = nullptr;
+            if (m_ok) {
+                if (sg.gidx) {
+                    const int gi = sg.gidx[(long)m * sg.gidx_stride];
+                    if (gi >= 0) arow = sg.base + (long)gi * sg.row_stride;
+                } else {
+                    arow = sg.base + (long)(m >> sg.row_shift) * sg.row_stride;
+                }
+            }
+            const float *ap = arow ? arow + (lo - qs) * 8 + lh * 4 : nullptr;
+            const float *bp = wrow + lo * 8;
+            int q = lo;
+            for (; q + 4 <= hi; q += 4) {
+                f32x4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    b[u] = *reinterpret_cast<const f32x4 *>(bp + u * 8);
+                    a[u] = ap ? *reinterpret_cast<const f32x4 *>(ap + u * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e], acc, 0, 0, 0);
+                bp += 32;
+                if (ap) ap += 32;
+            }
+            for (; q < hi; ++q) {
+                f32x4 b = *reinterpret_cast<const f32x4 *>(bp);
+                f32x4 a = ap ? *reinterpret_cast<const f32x4 *>(ap) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+                bp += 8;
+                if (ap) ap += 8;
+            }
+        }
+        qs += qlen;
+    }
+
+    // ---- cross-wave reduction through LDS, fixed summation order ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+
+    constexpr int RPW = 16 / W;   // accumulator registers finished by each wave
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        float v = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < W; ++w) v += red[w][r][lane];
+
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = n_ok && row < p.M;
+        const int rowc = row < p.M ? row : 0;
+        const int nc = n_ok ? n : 0;
+        if (p.bias) v += p.bias[nc];
+        if (p.add1) v += p.add1[(long)(rowc >> p.add1_shift) * p.add1_stride + nc];
+        if (p.add2) v += p.add2[(long)(rowc >> p.add2_shift) * p.add2_stride + nc];
+        if (p.epi == EPI_GATE) {
+            if (p.pre && ok) p.pre[(long)row * p.pre_stride + n] = v;
+            if (p.cls) v += p.cls[(long)p.label[rowc] * p.cls_ld + (nc % p.cls_ld)];
+            const float partner = __shfl_xor(v, 16);
+            if ((li & 16) == 0 && ok) {
+                const float gate = tanhf(v) * (1.0f / (1.0f + expf(-partner)));
+                const int tiles_per_group = p.gateD >> 4;
+                const int group = tile / tiles_per_group, ch0 = (tile - group * tiles_per_group) << 4;
+                p.out[(long)row * p.out_stride + group * p.gateD + ch0 + (li & 15)] = gate;
+            }
+        } else {
+            if (p.relu) v = v > 0.f ? v : 0.f;
+            if (ok) p.out[(long)row * p.out_stride + n] = v;
+        }
+    }
+}
+
+hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream) {
+    if (p.Ktot % 8 != 0 || p.M <= 0) return hipErrorInvalidValue;
+    int ntiles;
+    if (p.epi == EPI_GATE) {
+        if (p.gateD % 16 != 0 || p.N % (2 * p.gateD) != 0) return hipErrorInvalidValue;
+        ntiles = p.N / 32;
+    } else {
+        ntiles = (p.N + 31) / 32;
+    }
+    dim3 grid(ntiles, (p.M + 31) / 32);
+    // split K so that each wave runs ~32 k (16 MFMAs): short critical path, all loads issued up front
+    const int Q = p.Ktot / 8;
+    if (Q >= 64) hipLaunchKernelGGL(skinny_gemm_kernel<16>, grid, dim3(1024), 0, stream, p);
+    else if (Q >= 32) hipLaunchKernelGGL(skinny_gemm_kernel<8>, grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace ts

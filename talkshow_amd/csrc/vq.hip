@@ -1,0 +1,271 @@
+// VQ codebook search, gathers, the per-position sampler and small glue kernels.
+//
+//   vq_argmin   VectorQuantizerEMA.get_code_indices   nets/spg/vqvae_modules.py:311-319
+//   gather_rows VectorQuantizerEMA.quantize + the (B,W,64)->(B,64,W) permute of VQVAE.decode (a no-op in NLC)
+//               nets/spg/vqvae_modules.py:321-323, nets/spg/vqvae_1d.py:201-208
+//   sample      softmax + multinomial(1) of GatedPixelCNN.generate, or the greedy argmax harness
+//               nets/spg/gated_pixelcnn_v2.py:173-176
+#include "kernels.h"
+#include "../../include/talkshow_hip.h"
+
+namespace ts {
+
+// ---------------------------------------------------------------------------------------------------------------
+// vq_argmin: one workgroup = ROWS query rows x all codes.  Queries sit in LDS; each thread walks codes
+// j = tid, tid+256, ... (ascending, so a strict '<' keeps the lowest index on ties), reading the code row as
+// 16-byte loads straight from L2 (the 2048x64 fp32 codebook is 512 KiB and stays cache resident).  Distance is
+// evaluated in the reference's association: (|x|^2 + |e_j|^2) - 2*(x.e_j).  Block argmin = wavefront shuffle
+// reduction on (distance, index) pairs + one LDS hop across the 4 waves.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int VQ_ROWS = 8;
+
+__global__ __launch_bounds__(256) void vq_argmin_kernel(const float *__restrict__ x, int ldx, int M,
+                                                        const float *__restrict__ cb, const float *__restrict__ csq,
+                                                        int ncode, int dim, int64_t *idx, long idx_stride) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *xs = sm;                              // [VQ_ROWS][dim]
+    float *xsq = sm + VQ_ROWS * dim;             // [VQ_ROWS]
+    float *rd = xsq + VQ_ROWS;                   // [4][VQ_ROWS]
+    int *ri = reinterpret_cast<int *>(rd + 4 * VQ_ROWS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * VQ_ROWS;
+    for (int i = tid; i < VQ_ROWS * dim; i += 256) {
+        int r = i / dim, c = i - r * dim;
+        xs[i] = (m0 + r < M) ? x[(long)(m0 + r) * ldx + c] : 0.f;
+    }
+    __syncthreads();
+    if (tid < VQ_ROWS) {
+        float s = 0.f;
+        for (int c = 0; c < dim; ++c) s += xs[tid * dim + c] * xs[tid * dim + c];
+        xsq[tid] = s;
+    }
+    __syncthreads();
+
+    float best[VQ_ROWS];
+    int bidx[VQ_ROWS];
+#pragma unroll
+    for (int r = 0; r < VQ_ROWS; ++r) { best[r] = INFINITY; bidx[r] = 0x7fffffff; }
+
+    for (int j = tid; j < ncode; j += 256) {
+        float dot[VQ_ROWS];
+#pragma unroll
+        for (int r = 0; r < VQ_ROWS; ++r) dot[r] = 0.f;
+        const float4 *e = reinterpret_cast<const float4 *>(cb + (long)j * dim);
+        for (int c4 = 0; c4 < dim / 4; ++c4) {
+            const float4 ev = e[c4];
+#pragma unroll
+            for (int r = 0; r < VQ_ROWS; ++r) {
+                const float4 xv = *reinterpret_cast<const float4 *>(&xs[r * dim + c4 * 4]);
+                dot[r] = fmaf(xv.x, ev.x, dot[r]);
+                dot[r] = fmaf(xv.y, ev.y, dot[r]);
+                dot[r] = fmaf(xv.z, ev.z, dot[r]);
+                dot[r] = fmaf(xv.w, ev.w, dot[r]);
+            }
+        }
+        const float ee = csq[j];
+#pragma unroll
+        for (int r = 0; r < VQ_ROWS; ++r) {
+            const float d = (xsq[r] + ee) - 2.0f * dot[r];
+            if (d < best[r]) { best[r] = d; bidx[r] = j; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < VQ_ROWS; ++r) {
+        float d = best[r];
+        int j = bidx[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(d, off);
+            const int oj = __shfl_xor(j, off);
+            if (od < d || (od == d && oj < j)) { d = od; j = oj; }
+        }
+        if (lane == 0) { rd[wave * VQ_ROWS + r] = d; ri[wave * VQ_ROWS + r] = j; }
+    }
+    __syncthreads();
+    if (tid < VQ_ROWS && m0 + tid < M) {
+        float d = rd[tid];
+        int j = ri[tid];
+        for (int w = 1; w < 4; ++w) {
+            const float od = rd[w * VQ_ROWS + tid];
+            const int oj = ri[w * VQ_ROWS + tid];
+            if (od < d || (od == d && oj < j)) { d = od; j = oj; }
+        }
+        idx[(long)(m0 + tid) * idx_stride] = j;
+    }
+}
+
+hipError_t launch_vq_argmin(const float *x, int ldx, int M, const float *codebook, const float *code_sq, int ncode,
+                            int dim, int64_t *idx, long idx_stride, hipStream_t stream) {
+    if (dim % 4 != 0) return hipErrorInvalidValue;
+    size_t smem = (VQ_ROWS * dim + VQ_ROWS + 4 * VQ_ROWS) * sizeof(float) + 4 * VQ_ROWS * sizeof(int);
+    hipLaunchKernelGGL(vq_argmin_kernel, dim3((M + VQ_ROWS - 1) / VQ_ROWS), dim3(256), smem, stream, x, ldx, M,
+                       codebook, code_sq, ncode, dim, idx, idx_stride);
+    return hipGetLastError();
+}
+
+__global__ void row_sqnorm_kernel(const float *e, int n, int dim, float *out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < dim; ++c) s += e[(long)j * dim + c] * e[(long)j * dim + c];
+    out[j] = s;
+}
+hipError_t launch_row_sqnorm(const float *e, int n, int dim, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, e, n, dim, out);
+    return hipGetLastError();
+}
+
+// one wave per row, 16-byte lanes
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ table, int ld_table,
+                                                          const int64_t *__restrict__ idx, long idx_stride, int M,
+                                                          int width, float *__restrict__ out, int ldo) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float4 *src = reinterpret_cast<const float4 *>(table + idx[(long)m * idx_stride] * ld_table);
+    float4 *dst = reinterpret_cast<float4 *>(out + (long)m * ldo);
+    for (int c = lane; c < width / 4; c += 64) dst[c] = src[c];
+}
+hipError_t launch_gather_rows(const float *table, int ld_table, const int64_t *idx, long idx_stride, int M, int width,
+                              float *out, int ldo, hipStream_t stream) {
+    if (width % 4 || ld_table % 4 || ldo % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, table, ld_table, idx, idx_stride,
+                       M, width, out, ldo);
+    return hipGetLastError();
+}
+
+__global__ void pad_rows_kernel(const float *__restrict__ src, int lds_, int c, float *__restrict__ dst, int ldd,
+                                int cpad, long M) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * cpad) return;
+    const long m = i / cpad;
+    const int k = (int)(i - m * cpad);
+    dst[m * ldd + k] = k < c ? src[m * lds_ + k] : 0.f;
+}
+hipError_t launch_pad_rows(const float *src, int lds_, int c, float *dst, int ldd, int cpad, long M, hipStream_t stream) {
+    const long n = M * cpad;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, lds_, c, dst,
+                       ldd, cpad, M);
+    return hipGetLastError();
+}
+
+__global__ void i64_to_i32_kernel(const int64_t *src, int *dst, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (int)src[i];
+}
+hipError_t launch_i64_to_i32(const int64_t *src, int *dst, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(i64_to_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sampler: one workgroup per clip over V logits.
+//   greedy   : argmax, ties -> lowest index (torch.argmax on CPU returns the first maximum).
+//   sampling : inverse CDF of softmax(logits).  p_v ∝ exp(l_v - max); thread t owns the contiguous chunk
+//              [t*V/256, (t+1)*V/256), sums it left to right; thread 0 prefix-sums the 256 chunk sums left to right;
+//              the draw is the first index whose running sum exceeds u * total.  oracle/talkshow_oracle.py
+//              (`sample_inverse_cdf`) restates exactly this summation structure, so draws are comparable bit for bit.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                     uint32_t &o0) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0;
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
+    __shared__ float sf[256 + 1];
+    __shared__ int si[256];
+    __shared__ float s_thr;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *lg = p.logits + (long)b * p.V;
+
+    if (p.logits_copy)
+        for (int v = tid; v < p.V; v += 256) p.logits_copy[(long)b * p.copy_stride + v] = lg[v];
+
+    if (p.mode == TS_TEACHER_FORCED) {
+        if (tid == 0) p.tok32[(long)b * p.tok_stride] = (int)p.codes[(long)b * p.code_stride];
+        return;
+    }
+
+    // ---- max / argmax (needed by both modes) ----
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = tid; v < p.V; v += 256) {
+        const float x = lg[v];
+        if (x > best) { best = x; bi = v; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { sf[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    best = sf[0]; bi = si[0];
+    for (int w = 1; w < 4; ++w)
+        if (sf[w] > best || (sf[w] == best && si[w] < bi)) { best = sf[w]; bi = si[w]; }
+    __syncthreads();
+
+    int choice = bi;
+    if (p.mode != TS_SAMPLE_GREEDY) {
+        float u;
+        if (p.mode == TS_SAMPLE_UNIFORMS) {
+            u = p.uniforms[(long)b * p.u_stride];
+        } else {
+            const uint64_t clip = (uint64_t)(p.clip_index0 + b);
+            uint32_t r;
+            philox4x32_10(p.position, (uint32_t)clip, (uint32_t)(clip >> 32), 0u, (uint32_t)p.seed,
+                          (uint32_t)(p.seed >> 32), r);
+            u = (float)(r >> 8) * (1.0f / 16777216.0f);
+        }
+        const int chunk = (p.V + 255) / 256;
+        const int v0 = tid * chunk, v1 = min(v0 + chunk, p.V);
+        float s = 0.f;
+        for (int v = v0; v < v1; ++v) s += expf(lg[v] - best);
+        sf[tid + 1] = s;
+        __syncthreads();
+        if (tid == 0) {
+            float c = 0.f;
+            sf[0] = 0.f;
+            for (int t = 1; t <= 256; ++t) { c += sf[t]; sf[t] = c; }   // sf[t] = sum of chunks < t
+            s_thr = u * c;
+        }
+        __syncthreads();
+        const float thr = s_thr;
+        // owner: the first chunk whose inclusive prefix exceeds thr (the last non-empty chunk if none does)
+        const bool mine = (sf[tid] <= thr) && (thr < sf[tid + 1] || tid == 255);
+        if (mine && v0 < p.V) {
+            float c = sf[tid];
+            int k = v1 - 1;
+            for (int v = v0; v < v1; ++v) {
+                c += expf(lg[v] - best);
+                if (c > thr) { k = v; break; }
+            }
+            si[0] = k;
+        } else if (mine) {
+            si[0] = p.V - 1;
+        }
+        __syncthreads();
+        choice = si[0];
+    }
+    if (tid == 0) {
+        p.tok32[(long)b * p.tok_stride] = choice;
+        p.codes[(long)b * p.code_stride] = choice;
+    }
+}
+
+hipError_t launch_sample(const SampleParams &p, hipStream_t stream) {
+    hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace ts

@@ -1,0 +1,290 @@
+"""Module-shaped host objects over the C-ABI handles.
+
+The reference's wrappers expose `nn.Module`s (`.generator`, `.g_body`, `.g_hand`, `.audioencoder`) on which callers
+call `.eval()`, `.state_dict()`, `.load_state_dict()`, `.parameters()` and the model-specific entry points
+(`VQVAE.encode/decode/__call__`, `GatedPixelCNN.generate`, `AudioEncoder.__call__`).  These classes keep that
+surface — weights live in a CPU `OrderedDict` under the reference's key names — but every compute method goes to
+libtalkshow_hip.so.  There is no torch implementation behind them.
+
+Shape conventions of the methods follow the reference (channels-first tensors in, channels-first tensors out) so
+that `nets/` reads like the reference wrappers; the transposes to the library's NLC layout happen here, on device.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+
+
+class NativeModule:
+    """Weights in reference state_dict form + a lazily (re)built device handle."""
+
+    _schema_cache = {}
+
+    def __init__(self, schema_sd):
+        self._sd = OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in schema_sd.items())
+        self._handle = None
+        self._device = torch.device("cpu")
+        self.training = False
+
+    # --- nn.Module-like surface -------------------------------------------------------------------
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._sd.items())
+
+    def load_state_dict(self, sd, strict=True):
+        sd = OrderedDict((k.replace("module.", ""), v) for k, v in sd.items())
+        missing = [k for k in self._sd if k not in sd]
+        unexpected = [k for k in sd if k not in self._sd]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: "
+                               f"missing keys {missing[:5]}{'...' if len(missing) > 5 else ''}, "
+                               f"unexpected keys {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
+        for k, cur in self._sd.items():
+            if k not in sd:
+                continue
+            v = sd[k]
+            v = v.detach().cpu() if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+            if tuple(v.shape) != tuple(cur.shape):
+                raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)}, "
+                                   f"the shape in current model is {tuple(cur.shape)}")
+            self._sd[k] = v.to(cur.dtype).contiguous().clone()
+        self._after_load()
+        self._release()
+        return self
+
+    def _after_load(self):
+        pass
+
+    def parameters(self):
+        return (v for v in self._sd.values() if v.dtype == torch.float32)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("talkshow_amd is an inference path; training is out of scope (DESIGN.md)")
+        return self.eval()
+
+    def to(self, device):
+        self._device = torch.device(device)
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+
+    # --- native handle ---------------------------------------------------------------------------
+    def _release(self):
+        if self._handle is not None:
+            self._destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _require_hip(self):
+        if self._device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError(f"{type(self).__name__}: device is '{self._device}' and torch.cuda.is_available() is "
+                               f"{torch.cuda.is_available()}, but this implementation only runs on a HIP device "
+                               "(torch device 'cuda:N' on ROCm, MI355X / gfx950). There is no CPU path.")
+        return self._device.index if self._device.index is not None else torch.cuda.current_device()
+
+    def _ctx(self):
+        idx = self._require_hip()
+        torch.cuda.set_device(idx)
+        return _lib.context(idx)
+
+    def handle(self):
+        if self._handle is None:
+            self._handle = self._create(self._ctx())
+        return self._handle
+
+    def _dev(self):
+        return torch.device("cuda", self._require_hip())
+
+
+def _dev_f32(x, device):
+    return torch.as_tensor(x, dtype=torch.float32, device=device).contiguous()
+
+
+class AudioEncoder(NativeModule):
+    """`vqvae_1d.AudioEncoder(in_dim, num_hiddens, num_residual_layers, num_residual_hiddens)` (`vqvae_1d.py:11-34`)."""
+
+    def __init__(self, in_dim, num_hiddens, num_residual_layers, num_residual_hiddens=None):
+        self.in_dim, self.num_hiddens, self.nres = in_dim, num_hiddens, num_residual_layers
+        super().__init__(synth.audioencoder_state_dict(0, in_dim, num_hiddens, num_residual_layers))
+
+    def _create(self, ctx):
+        arr, n, keep = _lib.pack_state_dict(self._sd)
+        h = C.c_void_p()
+        _lib.check(_lib.load().ts_audioenc_create(ctx, arr, n, self.in_dim, self.num_hiddens, self.nres, C.byref(h)))
+        return h
+
+    def _destroy(self, h):
+        _lib.load().ts_convnet_destroy(h)
+
+    def forward_nlc(self, mfcc):
+        """mfcc (B,T,in_dim) device tensor -> (B,T//4,num_hiddens)."""
+        mfcc = _dev_f32(mfcc, self._dev())
+        B, T, _ = mfcc.shape
+        out = torch.empty((B, T // 2 // 2, self.num_hiddens), dtype=torch.float32, device=mfcc.device)
+        _lib.check(_lib.load().ts_audioenc_forward(self.handle(), _lib.dptr(mfcc), B, T, _lib.dptr(out), _lib.stream_ptr()))
+        return out
+
+    def __call__(self, x, frame_num=0):
+        """reference call shape: x (B,in_dim,T) -> (B,num_hiddens,T//4) (`vqvae_1d.py:27-34`)."""
+        x = _dev_f32(x, self._dev())
+        return self.forward_nlc(x.transpose(1, 2).contiguous()).transpose(1, 2)
+
+
+class VQVAE(NativeModule):
+    """`vqvae_1d.VQVAE(in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers, ·)` (`vqvae_1d.py:152-208`)."""
+
+    def __init__(self, in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers, num_residual_hiddens=None,
+                 commitment_cost=0.25, decay=0.99, share=False):
+        self.in_dim, self.embedding_dim, self.num_embeddings = in_dim, embedding_dim, num_embeddings
+        self.num_hiddens, self.nres = num_hiddens, num_residual_layers
+        super().__init__(synth.vqvae_state_dict(0, in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers))
+
+    def _create(self, ctx):
+        arr, n, keep = _lib.pack_state_dict(self._sd)
+        h = C.c_void_p()
+        _lib.check(_lib.load().ts_vqvae_create(ctx, arr, n, self.in_dim, self.embedding_dim, self.num_embeddings,
+                                               self.num_hiddens, self.nres, C.byref(h)))
+        return h
+
+    def _destroy(self, h):
+        _lib.load().ts_vqvae_destroy(h)
+
+    # --- NLC device entry points ---
+    def encode_nlc(self, poses, want_z=False, want_quantized=True):
+        poses = _dev_f32(poses, self._dev())
+        B, T, _ = poses.shape
+        H = T // 2 // 2
+        lat = torch.empty((B, H), dtype=torch.int64, device=poses.device)
+        z = torch.empty((B, H, self.embedding_dim), dtype=torch.float32, device=poses.device) if want_z else None
+        q = torch.empty((B, H, self.embedding_dim), dtype=torch.float32, device=poses.device) if want_quantized else None
+        _lib.check(_lib.load().ts_vqvae_encode(self.handle(), _lib.dptr(poses), B, T, _lib.dptr(z), _lib.dptr(lat),
+                                               _lib.dptr(q), _lib.stream_ptr()))
+        return z, q, lat
+
+    def decode_nlc(self, latents, out=None, col0=0):
+        latents = torch.as_tensor(latents, dtype=torch.int64, device=self._dev()).contiguous()
+        B, H = latents.shape
+        if out is None:
+            out = torch.empty((B, 4 * H, self.in_dim), dtype=torch.float32, device=latents.device)
+        _lib.check(_lib.load().ts_vqvae_decode(self.handle(), _lib.dptr(latents), B, H, _lib.dptr(out), out.shape[-1], col0,
+                                               _lib.stream_ptr()))
+        return out
+
+    def forward_nlc(self, poses, out=None, col0=0):
+        poses = _dev_f32(poses, self._dev())
+        B, T, _ = poses.shape
+        H = T // 2 // 2
+        lat = torch.empty((B, H), dtype=torch.int64, device=poses.device)
+        if out is None:
+            out = torch.empty((B, 4 * H, self.in_dim), dtype=torch.float32, device=poses.device)
+        _lib.check(_lib.load().ts_vqvae_forward(self.handle(), _lib.dptr(poses), B, T, _lib.dptr(lat), _lib.dptr(out),
+                                                out.shape[-1], col0, _lib.stream_ptr()))
+        return lat, out
+
+    # --- reference call shapes ---
+    def encode(self, gt_poses, id=None):
+        """`VQVAE.encode` (`vqvae_1d.py:196-199`): gt_poses (B,T,in_dim) -> (e (B,emb,H), latents (B,H))."""
+        _, q, lat = self.encode_nlc(gt_poses)
+        return q.transpose(1, 2), lat
+
+    def decode(self, b, w, e=None, latents=None, pre_state=None):
+        """`VQVAE.decode` (`vqvae_1d.py:201-208`): returns the reference's tuple (recon (B,in_dim,4w), None)."""
+        if e is not None:
+            raise NotImplementedError("decode(e=...) (continuous latents) is not on the inference path; pass latents=")
+        return self.decode_nlc(latents.reshape(b, w)).transpose(1, 2), None
+
+    def __call__(self, gt_poses, id=None, pre_state=None):
+        """`VQVAE.forward`, eval branch (`vqvae_1d.py:184-189`): (e, x_recon (B,in_dim,T))."""
+        _, q, lat = self.encode_nlc(gt_poses)
+        return q.transpose(1, 2), self.decode_nlc(lat).transpose(1, 2)
+
+
+class GatedPixelCNN(NativeModule):
+    """`gated_pixelcnn_v2.GatedPixelCNN(input_dim, dim, n_layers, n_classes, audio=True, bh_model=True)`."""
+
+    def __init__(self, input_dim=256, dim=64, n_layers=15, n_classes=10, audio=False, bh_model=False, aud_dim=256):
+        if not (audio and bh_model):
+            raise NotImplementedError("only the audio=True, bh_model=True configuration of config/body_pixel.json is built")
+        self.input_dim, self.dim, self.n_layers, self.n_classes, self.aud_dim = input_dim, dim, n_layers, n_classes, aud_dim
+        super().__init__(synth.pixelcnn_state_dict(0, input_dim, dim, n_layers, n_classes, aud_dim))
+
+    def _after_load(self):
+        # the reference zeroes these taps in place on every forward of layer 0 (make_causal, gated_pixelcnn_v2.py:57-63),
+        # so its state_dict() returns them zeroed after the first call; mirror that.
+        self._sd["layers.0.vert_stack.weight"][:, :, -1] = 0
+        self._sd["layers.0.horiz_stack.weight"][:, :, :, -1] = 0
+
+    def _create(self, ctx):
+        arr, n, keep = _lib.pack_state_dict(self._sd)
+        h = C.c_void_p()
+        _lib.check(_lib.load().ts_pixelcnn_create(ctx, arr, n, self.input_dim, self.dim, self.n_layers, self.n_classes,
+                                                  self.aud_dim, C.byref(h)))
+        return h
+
+    def _destroy(self, h):
+        _lib.load().ts_pixelcnn_destroy(h)
+
+    def run(self, label, aud_rows, mode=_lib.TS_SAMPLE_PHILOX, codes=None, uniforms=None, seed=0, clip_index0=0,
+            want_logits=False, pre_codes=None, pre_aud=None):
+        """aud_rows (B,H,aud_dim) device; returns (codes (B,H,2) int64, logits (B,H,2,V) or None)."""
+        dev = self._dev()
+        aud_rows = _dev_f32(aud_rows, dev)
+        B, H, _ = aud_rows.shape
+        label = torch.as_tensor(label, dtype=torch.int64, device=dev).reshape(-1).contiguous()
+        if label.numel() == 1 and B > 1:
+            label = label.repeat(B)
+        if mode == _lib.TS_TEACHER_FORCED:
+            codes = torch.as_tensor(codes, dtype=torch.int64, device=dev).contiguous()
+        else:
+            codes = torch.zeros((B, H, 2), dtype=torch.int64, device=dev)
+        logits = torch.empty((B, H, 2, self.input_dim), dtype=torch.float32, device=dev) if want_logits else None
+        if uniforms is not None:
+            uniforms = _dev_f32(uniforms, dev)
+        H0 = 0
+        if pre_codes is not None:
+            pre_codes = torch.as_tensor(pre_codes, dtype=torch.int64, device=dev).contiguous()
+            pre_aud = _dev_f32(pre_aud, dev)
+            H0 = pre_codes.shape[1]
+        _lib.check(_lib.load().ts_pixelcnn_generate(
+            self.handle(), _lib.dptr(label), _lib.dptr(aud_rows), B, H, mode, _lib.dptr(uniforms), int(seed) & (2 ** 64 - 1),
+            int(clip_index0), _lib.dptr(codes), _lib.dptr(logits), _lib.dptr(pre_codes), _lib.dptr(pre_aud), H0,
+            _lib.stream_ptr()))
+        return codes, logits
+
+    # --- reference call shapes ---
+    def generate(self, label, shape=(8, 8), batch_size=64, aud_feat=None, pre_latents=None, pre_audio=None,
+                 mode=None, seed=None, uniforms=None):
+        """`GatedPixelCNN.generate` (`gated_pixelcnn_v2.py:152-177`): aud_feat (B,aud_dim,H,2) -> codes (B,H,2).
+
+        Default is stochastic like the reference (softmax + one multinomial draw per position), with Philox uniforms
+        seeded from torch's default generator; `mode=TS_SAMPLE_GREEDY` gives the argmax harness.
+        """
+        if shape[1] != 2:
+            raise NotImplementedError("bh_model grids have exactly 2 columns (body, hand)")
+        rows = aud_feat[..., 0].transpose(1, 2)             # the 2 columns are copies (smplx_body_pixel.py:274)
+        pre_rows = pre_audio[..., 0].transpose(1, 2) if pre_audio is not None else None
+        if mode is None:
+            mode = _lib.TS_SAMPLE_PHILOX if uniforms is None else _lib.TS_SAMPLE_UNIFORMS
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        codes, _ = self.run(label, rows, mode=mode, uniforms=uniforms, seed=seed, pre_codes=pre_latents, pre_aud=pre_rows)
+        return codes
+
+    def __call__(self, x, label, aud=None):
+        """`GatedPixelCNN.forward` (`gated_pixelcnn_v2.py:130-150`): x (B,H,2) codes -> logits (B,input_dim,H,2)."""
+        rows = aud[..., 0].transpose(1, 2)
+        _, logits = self.run(label, rows, mode=_lib.TS_TEACHER_FORCED, codes=x, want_logits=True)
+        return logits.permute(0, 3, 1, 2)

@@ -1,0 +1,66 @@
+"""Multi-GPU driver pieces: one process per GPU, clips sharded by contiguous blocks, ONE exchange at the end.
+
+The reference has no distributed code.  Clips are independent (no cross-sample op anywhere,
+BatchNorm is in eval mode), so ranks never talk during generation; `gather_sequences` is the single RCCL all-gather
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests) of the generated pose sequences.
+Determinism contract: the result for global clip k does not depend on the world size — greedy decode is a pure
+function of the clip, and the stochastic sampler's Philox subsequence is the global clip index (clip_index0).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_clips, rank, world):
+    """Contiguous block of ceil(n/world) clips for `rank` (last ranks may get fewer / none): (start, stop)."""
+    per = (n_clips + world - 1) // world
+    start = min(rank * per, n_clips)
+    return start, min(start + per, n_clips)
+
+
+def gather_sequences(local, n_total=None):
+    """all-gather of (n_local, T, C) sequences -> (n_total, T, C) on every rank, in global clip order.
+
+    Ranks may hold different n_local (ragged tail): shards are padded to the largest block for the collective and
+    trimmed afterwards.  Without an initialised process group this is the identity.
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(counts)
+    if local.shape[0] < nmax:
+        pad = torch.zeros((nmax - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    out = torch.empty((world * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    parts = [out[r * nmax:r * nmax + counts[r]] for r in range(world)]
+    res = torch.cat(parts, 0)
+    if n_total is not None:
+        assert res.shape[0] == n_total, (res.shape, n_total)
+    return res
+
+
+def generate_sharded(generate_fn, mfcc, ids, batch=32):
+    """Run `generate_fn(mfcc_block, ids_block, clip_index0)` over this rank's shard in batches and all-gather.
+
+    mfcc (N,T,64) / ids (N,) are the GLOBAL inputs (every rank holds them, or at least its own block).
+    generate_fn returns (codes, poses) for a block; returns (N,T',C) poses on every rank.
+    """
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    n = mfcc.shape[0]
+    a, b = shard_range(n, rank, world)
+    outs = []
+    for s in range(a, b, batch):
+        e = min(s + batch, b)
+        _, poses = generate_fn(mfcc[s:e], ids[s:e], s)
+        outs.append(poses)
+    if outs:
+        local = torch.cat(outs, 0)
+    else:   # empty shard: shape must still be known for the collective
+        probe = torch.zeros((0,), dtype=torch.float32)
+        local = probe
+    return local, (a, b)

@@ -157,4 +157,4 @@ def speaker_ids(B):
 
 def to_torch(sd):
     import torch
-    return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in sd.items())
+    return OrderedDict((k, torch.from_numpy(np.array(v, copy=True, order='C'))) for k, v in sd.items())

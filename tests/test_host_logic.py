@@ -1,0 +1,118 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, the wrappers keep the reference's
+checkpoint / call-surface contract, and nothing silently falls back to a CPU implementation."""
+import argparse
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from talkshow_amd import synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from talkshow_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "talkshow_hip.h")).read()
+    declared = set(re.findall(r"\b(ts_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ts_tensor"}
+    lib = _lib.load()                       # raises if the .so is missing: there is no fallback
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/talkshow_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
+    assert lib.ts_version().decode().startswith("talkshow_hip")
+    # no compute without a GPU: asking for a context must fail loudly, not fall back
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="HIP device"):
+            _lib.context(0)
+
+
+def test_no_oracle_import_in_product_code():
+    """The oracle is test infrastructure: nothing under talkshow_amd/ or nets/ may import it."""
+    for root in ("talkshow_amd", "nets"):
+        for dp, _, files in os.walk(os.path.join(REPO, root)):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(dp, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"{dp}/{f} imports the oracle"
+
+
+def _config(tmp_path, which):
+    from talkshow_amd.config import Object
+    cfg = json.load(open(os.path.join(REPO, "config", which + ".json")))
+    if "vq_path" in cfg["Model"]:
+        p = str(tmp_path / "vq.pth")
+        small = dict(num_embeddings=2048, num_hiddens=1024)
+        torch.save({"generator": {"g_body": synth.to_torch(synth.vqvae_state_dict(seed=1, in_dim=39, **small)),
+                                  "g_hand": synth.to_torch(synth.vqvae_state_dict(seed=1, in_dim=90, salt=1, **small))}}, p)
+        cfg["Model"]["vq_path"] = p
+    return Object(cfg)
+
+
+def test_init_model_surface(tmp_path):
+    import nets
+    from nets.init_model import init_model
+    for name in ("s2g_face", "s2g_body_vq", "s2g_body_pixel", "s2g_body_ae", "LS3DCG", "TrainWrapperBaseClass",
+                 "normalize", "denormalize"):
+        assert hasattr(nets, name)
+    with pytest.raises(ValueError):
+        init_model("nope", None, None)
+    args = argparse.Namespace(gpu="cpu", infer=True)
+    w = init_model("s2g_body_pixel", args, _config(tmp_path, "body_pixel"))
+    assert w.each_dim == [0, 39, 90, 100] and len(w.c_index) == 129 and w.num_classes == 4
+    for attr in ("generator", "g_body", "g_hand", "audioencoder", "device"):
+        assert hasattr(w, attr)
+    # VQ checkpoint was loaded by the constructor (smplx_body_pixel.py:59-62)
+    ref = synth.vqvae_state_dict(seed=1, in_dim=39)
+    np.testing.assert_array_equal(w.g_body.state_dict()["decoder.project.weight"].numpy(), ref["decoder.project.weight"])
+    # checkpoint round trip incl. DataParallel 'module.' prefixes and optimiser entries (smplx_body_pixel.py:115-142)
+    gen = synth.to_torch(synth.pixelcnn_state_dict(seed=2))
+    aud = synth.to_torch(synth.audioencoder_state_dict(seed=2))
+    w.load_state_dict({"generator": {"module." + k: v for k, v in gen.items()}, "audioencoder": aud,
+                       "generator_optim": {"state": {}}, "audioencoder_optim": None, "discriminator": None})
+    sd = w.state_dict()
+    assert list(sd["generator"].keys()) == list(gen.keys())
+    np.testing.assert_array_equal(sd["audioencoder"]["project.conv.weight"].numpy(), aud["project.conv.weight"].numpy())
+    assert float(sd["generator"]["layers.0.horiz_stack.weight"][..., -1].abs().max()) == 0.0     # mask 'A' applied
+    np.testing.assert_array_equal(sd["generator"]["layers.1.horiz_stack.weight"].numpy(),
+                                  gen["layers.1.horiz_stack.weight"].numpy())
+    with pytest.raises(RuntimeError, match="size mismatch|missing"):
+        w.generator.load_state_dict({k: v[..., :1] if v.ndim == 4 else v for k, v in gen.items()})
+    w.generator.eval(); w.g_body.eval(); w.g_hand.eval(); w.audioencoder.eval()
+    # no CPU path: inference without a HIP device fails loudly
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="HIP device|no CPU path"):
+            w.infer_on_audio(synth.mfcc_features(0, 1, 60)[0], id=torch.tensor([0]), fps=30, B=1)
+    with pytest.raises(AssertionError):
+        argsT = argparse.Namespace(gpu="cpu", infer=False)
+        init_model("s2g_body_pixel", argsT, _config(tmp_path, "body_pixel")).infer_on_audio(np.zeros((60, 64), np.float32))
+    with pytest.raises(NotImplementedError):
+        w.infer_on_audio("some.wav", id=torch.tensor([0]))
+
+
+def test_body_vq_wrapper_surface(tmp_path):
+    from nets.init_model import init_model
+    args = argparse.Namespace(gpu="cpu", infer=True)
+    w = init_model("s2g_body_vq", args, _config(tmp_path, "body_vq"))
+    b, h = synth.to_torch(synth.vqvae_state_dict(seed=4, in_dim=39)), synth.to_torch(synth.vqvae_state_dict(seed=4, in_dim=90, salt=1))
+    w.load_state_dict({"g_body": b, "g_hand": h})
+    sd = w.state_dict()
+    assert set(sd) >= {"g_body", "g_hand"} and list(sd["g_hand"].keys()) == list(h.keys())
+    with pytest.raises(ValueError):
+        w.infer_on_audio(torch.zeros(1, 64, 60))
+
+
+def test_out_of_scope_names_say_so():
+    import nets
+    for cls in (nets.s2g_body_ae, nets.LS3DCG, nets.s2g_face):
+        with pytest.raises(NotImplementedError):
+            cls(None, None)
+
+
+def test_pose_index_matches_reference_layout():
+    from talkshow_amd.pose_index import c_index_3d
+    g = np.load(os.path.join(REPO, "tests", "golden", "body_vq_e2e_full.npz"))
+    np.testing.assert_array_equal(c_index_3d, g["c_index"])      # c_index_3d as the reference computes it

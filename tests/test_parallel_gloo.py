@@ -1,0 +1,54 @@
+"""world_size-2 gloo test of the N>1 path: block sharding + the single all-gather, incl. a ragged tail."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from talkshow_amd.parallel import gather_sequences, generate_sharded, shard_range
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 32, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_range(n, r, world) for r in range(world)]
+            flat = [i for a, b in blocks for i in range(a, b)]
+            assert flat == list(range(n))
+
+
+def _fake_generate(mfcc, ids, clip_index0):
+    # a pure per-clip function standing in for the HIP path: depends on the clip's data and its GLOBAL index only
+    n = mfcc.shape[0]
+    idx = torch.arange(clip_index0, clip_index0 + n, dtype=torch.float32).view(n, 1, 1)
+    poses = mfcc.mean(-1, keepdim=True).repeat(1, 1, 3) + idx + ids.view(n, 1, 1).float()
+    return None, poses
+
+
+def _worker(rank, world, port, n, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    mfcc = torch.randn(n, 8, 4, generator=g)
+    ids = torch.arange(n) % 4
+    local, (a, b) = generate_sharded(_fake_generate, mfcc, ids, batch=3)
+    allp = gather_sequences(local, n_total=n)
+    if rank == 0:
+        torch.save(allp, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [8, 7])
+def test_two_ranks_equal_one(tmp_path, n):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "all.pt")
+    mp.spawn(_worker, args=(2, port, n, out), nprocs=2, join=True)
+    got = torch.load(out)
+    g = torch.Generator().manual_seed(0)
+    mfcc = torch.randn(n, 8, 4, generator=g)
+    _, ref = _fake_generate(mfcc, torch.arange(n) % 4, 0)
+    assert got.shape == ref.shape
+    np.testing.assert_array_equal(got.numpy(), ref.numpy())      # same answer for 1 and 2 ranks
