@@ -60,7 +60,7 @@ __global__ __launch_bounds__(W * 64) void skinny_gemm_kernel(const SkinnyParams 
                 if (sg.gidx) {
                     const int gi = sg.gidx[(long)m * sg.gidx_stride];
                     if (gi >= 0) arow = sg.base + (long)gi * sg.row_stride;
-                } else {
+                } else if (sg.base) {   // a null dense segment is a block of zero rows (row above the grid)
                     arow = sg.base + (long)(m >> sg.row_shift) * sg.row_stride;
                 }
             }

@@ -75,7 +75,8 @@ def test_op_vq_argmin(hip, M, ncode, dim):
     cb[7] = cb[3]                       # an exact tie between codes 3 and 7 ...
     x[0] = cb[3]                        # ... which row 0 hits: lowest index must win
     idx = torch.empty(M, dtype=torch.int64, device="cuda")
-    _lib.check(lib.ts_op_vq_argmin(ctx, _lib.dptr(dev(x)), M, _lib.dptr(dev(cb)), ncode, dim, _lib.dptr(idx), None))
+    xd, cbd = dev(x), dev(cb)           # keep the device tensors alive across the call
+    _lib.check(lib.ts_op_vq_argmin(ctx, _lib.dptr(xd), M, _lib.dptr(cbd), ncode, dim, _lib.dptr(idx), None))
     ref = O.vq_get_code_indices(x, cb)
     got = idx.cpu().numpy()
     assert got[0] == 3
@@ -96,7 +97,8 @@ def test_op_linear(hip, M, K, N, relu):
     w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
     out = torch.empty((M, N), dtype=torch.float32, device="cuda")
-    _lib.check(lib.ts_op_linear(ctx, _lib.dptr(dev(x)), M, K, _lib.fptr(w), _lib.fptr(b), N, relu, _lib.dptr(out), None))
+    xd = dev(x)
+    _lib.check(lib.ts_op_linear(ctx, _lib.dptr(xd), M, K, _lib.fptr(w), _lib.fptr(b), N, relu, _lib.dptr(out), None))
     ref = x @ w.T + b
     if relu:
         ref = np.maximum(ref, 0)
@@ -117,7 +119,8 @@ def test_op_sample(hip):
     assert got[1] == 100
     u = rng.random(B).astype(np.float32)
     u[0], u[2] = 0.0, np.float32(1.0 - 2 ** -24)
-    _lib.check(lib.ts_op_sample(ctx, _lib.dptr(ld), B, V, _lib.TS_SAMPLE_UNIFORMS, _lib.dptr(dev(u)), _lib.dptr(idx), None))
+    ud = dev(u)
+    _lib.check(lib.ts_op_sample(ctx, _lib.dptr(ld), B, V, _lib.TS_SAMPLE_UNIFORMS, _lib.dptr(ud), _lib.dptr(idx), None))
     ref = O.sample_inverse_cdf(logits, u)
     got = idx.cpu().numpy()
     # expf on the device and np.exp on the host may differ in the last bit: allow a draw to move by one slot at a boundary
