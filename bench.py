@@ -22,6 +22,9 @@ import os
 import sys
 import time
 
+# independent batches are pipelined over several HIP streams; give each its own hardware queue
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -66,12 +69,66 @@ def cpu_baseline(sds, seed):
             "sample": f"1 clip (10 s, 300 frames), VQ encode + greedy full-grid PixelCNN + VQ decode, numpy/BLAS fp32, {dt:.1f} s"}
 
 
+
+def roofline_block(w, lib, _lib, stream, mfcc, ids, B, H, local, step):
+    """Roofline of the dominant kernel + per-family breakdown.
+
+    Dominant kernel (≈85 % of a batch's device time): skinny_gemm_f32, the per-position GEMM of the PixelCNN chain.
+    Its launches are replayed from one hipGraph per batch, so the live measurement is: HIP events recorded on the launch
+    stream around one replay (5 repeats, median) / the number of skinny launches inside (ts_pixelcnn_graph_stats, which
+    also gives the algorithmic flops 2*M*N*K summed over those launches).  The 150 sampler launches inside the same
+    replay are <2 % of it.  conv_gemm_f32 (VQ encoder/decoder, audio encoder) is measured with HIP event pairs around
+    every launch on the launch stream (ts_prof_*).
+    """
+    res = {}
+    with torch.cuda.stream(stream):
+        feat = w.audioencoder.forward_nlc(mfcc)
+        w.generator.run(ids, feat, mode=_lib.TS_SAMPLE_GREEDY)
+        times = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            w.generator.run(ids, feat, mode=_lib.TS_SAMPLE_GREEDY)
+            e1.record(stream)
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        n, fl = C.c_int64(), C.c_double()
+        _lib.check(lib.ts_pixelcnn_graph_stats(w.generator.handle(), C.c_void_p(stream.cuda_stream), B, H,
+                                               _lib.TS_SAMPLE_GREEDY, C.byref(n), C.byref(fl)))
+    ms = sorted(times)[len(times) // 2]
+    ach = fl.value / (ms * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("skinny_gemm_f32", {}).get("hbm_bytes_per_launch")
+    res["roofline"] = {"kernel": "skinny_gemm_f32 (PixelCNN per-position GEMM chain)", "bound": "mfma", "achieved": ach,
+                       "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                       "traffic": traffic, "launches_per_batch": n.value, "avg_launch_us": ms * 1e3 / n.value,
+                       "flops_per_launch": fl.value / n.value, "chain_ms_per_batch": ms}
+    # per-family pass: event pair around every launch (eager launches, so the chain is slower here than in production)
+    ctx = _lib.context(local)
+    _lib.check(lib.ts_prof_enable(ctx, 1))
+    step(0)
+    torch.cuda.synchronize()
+    msf, nf, flf = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
+    _lib.check(lib.ts_prof_read(ctx, msf, nf, flf, 1))
+    _lib.check(lib.ts_prof_enable(ctx, 0))
+    ach_c = flf[0] / (msf[0] * 1e-3) / 1e12
+    res["roofline_conv_gemm"] = {"kernel": "conv_gemm_f32 (VQ encoder/decoder + audio encoder layers)", "bound": "mfma",
+                                 "achieved": ach_c, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": ach_c / PEAK_FP32_MFMA_TFLOPS, "launches_per_batch": nf[0],
+                                 "avg_launch_us": msf[0] * 1e3 / nf[0], "ms_per_batch": msf[0]}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("TS_BENCH_STREAMS", "4")),
+                    help="independent steps (batches of 32 clips) in flight at once, one HIP stream each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -98,34 +155,40 @@ def main():
     gt = [torch.from_numpy(synth.gt_poses(2000 + 10 * rank + k, B, T)).to(dev) for k in range(NB)]
     ids = torch.from_numpy(synth.speaker_ids(B)).to(dev)
     H = T // 4
-    gt_codes = torch.empty((B, H, 2), dtype=torch.int64, device=dev)
-    lat_b = torch.empty((B, H), dtype=torch.int64, device=dev)
-    lat_h = torch.empty((B, H), dtype=torch.int64, device=dev)
+    S = max(1, a.streams)
+    streams = _lib.create_streams(S, local)
+    lat_b = [torch.empty((B, H), dtype=torch.int64, device=dev) for _ in range(S)]
+    lat_h = [torch.empty((B, H), dtype=torch.int64, device=dev) for _ in range(S)]
     gt_body = [g[..., :39].contiguous() for g in gt]
     gt_hand = [g[..., 39:].contiguous() for g in gt]
 
     def step(k):
-        s = _lib.stream_ptr()
-        # VQ-VAE encode half of configs[1] (VQVAE.encode of the 300 GT frames, body and hand)
-        _lib.check(lib.ts_vqvae_encode(w.g_body.handle(), _lib.dptr(gt_body[k % NB]), B, T, None, _lib.dptr(lat_b), None, s))
-        _lib.check(lib.ts_vqvae_encode(w.g_hand.handle(), _lib.dptr(gt_hand[k % NB]), B, T, None, _lib.dptr(lat_h), None, s))
-        # audio encoder -> PixelCNN greedy -> VQ decode
-        return w.generate_batch(mfcc[k % NB], ids, mode=_lib.TS_SAMPLE_GREEDY, clip_index0=rank * B)
+        # one complete pass over one batch of 32 clips, enqueued on stream k % S (the library keeps one scratch arena
+        # per stream; weights are shared)
+        with torch.cuda.stream(streams[k % S]):
+            s = _lib.stream_ptr()
+            # VQ-VAE encode half of configs[1] (VQVAE.encode of the 300 GT frames, body and hand)
+            _lib.check(lib.ts_vqvae_encode(w.g_body.handle(), _lib.dptr(gt_body[k % NB]), B, T, None, _lib.dptr(lat_b[k % S]), None, s))
+            _lib.check(lib.ts_vqvae_encode(w.g_hand.handle(), _lib.dptr(gt_hand[k % NB]), B, T, None, _lib.dptr(lat_h[k % S]), None, s))
+            # audio encoder -> PixelCNN greedy -> VQ decode
+            return w.generate_batch(mfcc[k % NB], ids, mode=_lib.TS_SAMPLE_GREEDY, clip_index0=rank * B)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for k in range(a.warmup):
+    torch.cuda.synchronize()
+    for k in range(max(a.warmup, S)):      # at least one pass per stream: graph capture + scratch allocation are warm-up
         step(k)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
         codes, poses = step(k)
+    torch.cuda.synchronize()
     if world > 1:
         all_poses = gather_sequences(poses)            # the one exchange: (N*B, 300, 129) on every rank
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -140,32 +203,23 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded MFCC-scale features / poses, random-init weights of the reference architecture)",
         "config": {"workload": "BASELINE configs[1]: batch=32 x 10 s clips, body+hand VQ-VAE encode -> PixelCNN greedy decode -> VQ decode, 30 fps",
-                   "batch_per_gpu": B, "frames_per_clip": FRAMES_PER_CLIP, "parallelism": f"clip-sharded x{world}"},
+                   "batch_per_gpu": B, "frames_per_clip": FRAMES_PER_CLIP,
+                   "parallelism": f"clip-sharded x{world}, {S} batches in flight per GPU (one HIP stream each)"},
         "per_gpu_frames_per_s": frames / dt / world,
+        "streams": S,
     }
+    # latency of ONE isolated batch (a single stream, nothing else in flight)
+    lat = []
+    for k in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(0)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    out["batch_latency_ms"] = sorted(lat)[1] * 1e3
 
     if rank == 0 and not a.no_roofline:
-        # instrumented pass (HIP events around every launch, on the launch stream): per-kernel-family device time
-        ctx = _lib.context(local)
-        _lib.check(lib.ts_prof_enable(ctx, 1))
-        nprof = 2
-        for k in range(nprof):
-            step(k)
-        ms = (C.c_double * 3)()
-        n = (C.c_int64 * 3)()
-        fl = (C.c_double * 3)()
-        _lib.check(lib.ts_prof_read(ctx, ms, n, fl, 1))
-        _lib.check(lib.ts_prof_enable(ctx, 0))
-        fam = ["conv_gemm_f32", "skinny_gemm_f32", "vq/sample/glue"]
-        per = {fam[i]: {"ms_per_step": ms[i] / nprof, "launches_per_step": n[i] / nprof,
-                        "avg_launch_us": (ms[i] / n[i] * 1e3) if n[i] else None,
-                        "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if ms[i] > 0 and fl[i] > 0 else None} for i in range(3)}
-        dom = max(range(2), key=lambda i: ms[i])
-        ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
-        out["roofline"] = {"kernel": fam[dom], "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                           "avg_launch_us": per[fam[dom]]["avg_launch_us"], "launches_per_step": per[fam[dom]]["launches_per_step"]}
-        out["kernel_families"] = per
+        out.update(roofline_block(w, lib, _lib, streams[0], mfcc[0], ids, B, H, local, step))
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sds, 1000)
     if rank == 0:

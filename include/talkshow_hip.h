@@ -47,6 +47,10 @@ void ts_ctx_destroy(ts_ctx *ctx);
 const char *ts_last_error(void);
 /* library / build identification, e.g. "talkshow_hip 0.1 gfx950" */
 const char *ts_version(void);
+/* Non-blocking HIP streams for keeping several independent batches in flight on one GPU (the library keeps one
+ * scratch arena per stream; weights are shared).  *out is a hipStream_t. */
+int ts_stream_create(ts_ctx *ctx, void **out);
+int ts_stream_destroy(ts_ctx *ctx, void *stream);
 
 /* ---- AudioEncoder(in_dim=64, num_hiddens, num_residual_layers, ·)  — vqvae_1d.py:11-34 ------------------ */
 int ts_audioenc_create(ts_ctx *ctx, const ts_tensor *sd, int n, int in_dim, int num_hiddens,
@@ -99,6 +103,10 @@ int ts_pixelcnn_generate(ts_pixelcnn *pix, const int64_t *label_dev, const float
                          float *logits_dev, const int64_t *pre_codes_dev, const float *pre_aud_dev, int H0,
                          void *stream);
 
+/* Launch count and algorithmic flops (2*M*N*K over every skinny_gemm launch) of the hipGraph captured for
+ * (B, H, mode) on `stream` — what one replay executes; used by bench.py for the roofline line. */
+int ts_pixelcnn_graph_stats(ts_pixelcnn *pix, void *stream, int B, int H, int mode, int64_t *launches, double *flops);
+
 /* ---- whole wrappers --------------------------------------------------------------------------------------- */
 /* s2g_body_pixel.TrainWrapper.infer_on_audio after the MFCC front-end (smplx_body_pixel.py:272-285):
  * mfcc_dev (B,T,64), ids_dev (B,) int64 -> codes_dev (B,H,2) int64, poses_dev (B,4H,body_dim+hand_dim). */
@@ -138,6 +146,10 @@ int ts_op_sample(ts_ctx *ctx, const float *logits_dev, int B, int V, int mode, c
 int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
                        const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
                        void *stream);
+
+/* Tuning entry (not part of the drop-in surface): `iters` DEPENDENT skinny_gemm launches replayed from one hipGraph;
+ * *us_out = microseconds per launch.  gate != 0: N = 2K with the tanh*sigmoid epilogue; debug: ablation bits. */
+int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int debug, float *us_out);
 
 /* ---- instrumentation ---------------------------------------------------------------------------------------- */
 /* Per-kernel-family device time of the calls made on this context since the last reset, measured with HIP

@@ -28,6 +28,8 @@ SIGNATURES = {
     "ts_ctx_destroy": (None, [_vp]),
     "ts_last_error": (C.c_char_p, []),
     "ts_version": (C.c_char_p, []),
+    "ts_stream_create": (_i, [_vp, C.POINTER(_vp)]),
+    "ts_stream_destroy": (_i, [_vp, _vp]),
     "ts_audioenc_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, C.POINTER(_vp)]),
     "ts_convnet_destroy": (None, [_vp]),
     "ts_audioenc_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
@@ -39,6 +41,7 @@ SIGNATURES = {
     "ts_pixelcnn_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ts_pixelcnn_destroy": (None, [_vp]),
     "ts_pixelcnn_generate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ts_pixelcnn_graph_stats": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "ts_body_pixel_infer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _u64, _i64, _vp, _vp, _vp]),
     "ts_body_vq_infer": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ts_op_conv1d": (_i, [_vp, _vp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -46,6 +49,7 @@ SIGNATURES = {
     "ts_op_vq_argmin": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "ts_op_linear": (_i, [_vp, _vp, _i, _i, _fp, _fp, _i, _i, _vp, _vp]),
     "ts_op_sample": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ts_debug_skinny_chain": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
     "ts_prof_enable": (_i, [_vp, _i]),
     "ts_prof_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _i]),
 }
@@ -115,6 +119,18 @@ def pack_state_dict(sd):
         else:
             arr[k].data = None
     return arr, len(items), keep
+
+
+def create_streams(n, device_index=None):
+    """n library-created HIP streams wrapped as torch ExternalStreams (created back to back -> distinct HW queues)."""
+    ctx = context(device_index)
+    out = []
+    for _ in range(n):
+        h = _vp()
+        check(load().ts_stream_create(ctx, C.byref(h)))
+        out.append(torch.cuda.ExternalStream(h.value, device=torch.device("cuda", device_index if device_index is not None
+                                                                              else torch.cuda.current_device())))
+    return out
 
 
 _contexts = {}

@@ -8,14 +8,32 @@ struct BodyWork {
     DevBuf feat;
     DevBuf lat[2];
 };
-// scratch between the stages of ts_body_pixel_infer: audio feature map, split latents
-BodyWork &body_work() {
-    static thread_local BodyWork w;
-    return w;
+// scratch between the stages of ts_body_pixel_infer (audio feature map, split latents), one set per stream
+BodyWork &body_work(hipStream_t s) {
+    static thread_local std::map<hipStream_t, std::unique_ptr<BodyWork>> m;
+    auto &w = m[s];
+    if (!w) w.reset(new BodyWork());
+    return *w;
 }
 }  // namespace
 
 extern "C" {
+
+// Streams for pipelining independent batches.  Created back to back so that ROCclr's round-robin hands consecutive
+// streams distinct hardware queues (GPU_MAX_HW_QUEUES); hosts without a stream pool of their own use these.
+int ts_stream_create(ts_ctx *ctx, void **out) {
+    if (!ctx || !out) return fail("ts_stream_create: null argument");
+    TS_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = nullptr;
+    TS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = s;
+    return 0;
+}
+int ts_stream_destroy(ts_ctx *ctx, void *stream) {
+    if (!ctx) return fail("ts_stream_destroy: null ctx");
+    TS_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
 
 // s2g_body_pixel.TrainWrapper.infer_on_audio, device part (nets/smplx_body_pixel.py:272-285)
 int ts_body_pixel_infer(ts_convnet *ae, ts_pixelcnn *pix, ts_vqvae *vb, ts_vqvae *vh, const float *mfcc,
@@ -26,7 +44,7 @@ int ts_body_pixel_infer(ts_convnet *ae, ts_pixelcnn *pix, ts_vqvae *vb, ts_vqvae
     const int H = (T / 2) / 2;
     if (H < 1) return fail("ts_body_pixel_infer: clip too short");
     const int aud_dim = convnet_hidden(ae), body_dim = vqvae_in_dim(vb), hand_dim = vqvae_in_dim(vh);
-    BodyWork &w = body_work();
+    BodyWork &w = body_work(s);
     TS_TRY(w.feat.ensure((size_t)B * H * aud_dim * sizeof(float)));
     TS_TRY(ts_audioenc_forward(ae, mfcc, B, T, w.feat.f(), s));
     TS_TRY(ts_pixelcnn_generate(pix, ids, w.feat.f(), B, H, mode, uniforms, seed, clip0, codes, nullptr, nullptr, nullptr,
@@ -162,6 +180,71 @@ int ts_op_linear(ts_ctx *ctx, const float *x, int M, int K, const float *w, cons
     q.out_stride = N;
     TS_TRY(run_skinny(ctx, q, s));
     TS_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+// Tuning entry (not part of the drop-in surface): `iters` DEPENDENT skinny_gemm launches (stage i reads stage i-1's
+// output) captured in one hipGraph and replayed; *us_out = microseconds per launch.  M x K activations, N = K outputs
+// (linear) or 2K (gate epilogue, so the chain closes on itself); debug = ablation bits of skinny_gemm_kernel_v2.
+int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int debug, float *us_out) {
+    if (!ctx || !us_out) return fail("ts_debug_skinny_chain: null argument");
+    const int N = gate ? 2 * K : K;
+    DevBuf w, bias, x0, x1, lab, cls;
+    std::vector<float> hw((size_t)N * K), hb(N, 0.01f), hx((size_t)M * K, 0.5f), hc((size_t)4 * N, 0.01f);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = ((int)(i * 2654435761u >> 16) % 2001 - 1000) * (1.0f / (1000.f * K));
+    std::vector<int> hl(M, 1);
+    TS_TRY(w.upload(hw.data(), hw.size() * 4));
+    TS_TRY(bias.upload(hb.data(), hb.size() * 4));
+    TS_TRY(x0.upload(hx.data(), hx.size() * 4));
+    TS_TRY(x1.upload(hx.data(), hx.size() * 4));
+    TS_TRY(lab.upload(hl.data(), hl.size() * 4));
+    TS_TRY(cls.upload(hc.data(), hc.size() * 4));
+    hipStream_t s;
+    TS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipGraph_t g;
+    hipGraphExec_t ex;
+    TS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < iters; ++i) {
+        SkinnyParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.M = M;
+        q.N = N;
+        q.nseg = 1;
+        q.Ktot = K;
+        q.seg[0].base = (i & 1) ? x1.f() : x0.f();
+        q.seg[0].row_stride = K;
+        q.seg[0].len = K;
+        q.W = w.f();
+        q.ldw = K;
+        q.bias = bias.f();
+        q.epi = gate ? EPI_GATE : EPI_LINEAR;
+        q.gateD = K;
+        q.cls = gate ? cls.f() : nullptr;
+        q.label = lab.i();
+        q.cls_ld = N;
+        q.out = (i & 1) ? x0.f() : x1.f();
+        q.out_stride = K;
+        q.debug = debug;
+        TS_HIP(launch_skinny_gemm(q, s));
+    }
+    TS_HIP(hipStreamEndCapture(s, &g));
+    TS_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    hipEvent_t a, b;
+    TS_HIP(hipEventCreate(&a));
+    TS_HIP(hipEventCreate(&b));
+    TS_HIP(hipGraphLaunch(ex, s));
+    TS_HIP(hipEventRecord(a, s));
+    TS_HIP(hipGraphLaunch(ex, s));
+    TS_HIP(hipEventRecord(b, s));
+    TS_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    TS_HIP(hipEventElapsedTime(&ms, a, b));
+    *us_out = ms * 1e3f / iters;
+    (void)hipGraphExecDestroy(ex);
+    (void)hipGraphDestroy(g);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipStreamDestroy(s);
     return 0;
 }
 

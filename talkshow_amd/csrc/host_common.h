@@ -125,6 +125,9 @@ struct Profiler {
 struct ts_ctx {
     int device = 0;
     ts::Profiler prof;
+    // always-on launch / algorithmic-flop counters per kernel family (cheap host-side bookkeeping)
+    long n_launch[ts::FAM_COUNT] = {0, 0, 0};
+    double n_flops[ts::FAM_COUNT] = {0, 0, 0};
     ts::DevBuf neg1;   // a single int32 -1 (gather index meaning "zero row")
 };
 
@@ -132,6 +135,7 @@ namespace ts {
 
 int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s);
 int run_skinny(ts_ctx *ctx, const SkinnyParams &p, hipStream_t s);
+int run_skinny2(ts_ctx *ctx, const SkinnyParams &p0, const SkinnyParams &p1, hipStream_t s);
 // misc launches are wrapped with this scope guard so they show up under FAM_MISC
 struct MiscScope {
     ts_ctx *ctx;

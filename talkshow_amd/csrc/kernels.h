@@ -85,9 +85,17 @@ struct SkinnyParams {
     long out_stride;
     float *pre;          // EPI_GATE optional: pre-activation (acc + bias + add1, without cls) [M][pre_stride]
     long pre_stride;
+    int grid_x, grid_y;  // filled by the launcher
+    int debug;           // ablation bits for tools/skinny_chain.py (0 in production)
+};
+
+struct SkinnyBatch {
+    SkinnyParams p[2];
 };
 
 hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream);
+// two independent problems in one launch (p1 may be null)
+hipError_t launch_skinny_gemm2(const SkinnyParams *p0, const SkinnyParams *p1, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // VQ / sampling / glue kernels
@@ -113,6 +121,7 @@ struct SampleParams {
     long u_stride;
     uint64_t seed;
     int64_t clip_index0;
+    const uint64_t *dyn;   // optional device words {seed, clip_index0} overriding the two fields above (graph replay)
     uint32_t position;     // Philox counter word: linear position (row*2 + col)
     int *tok32;            // token for clip b written to tok32[b * tok_stride]
     long tok_stride;

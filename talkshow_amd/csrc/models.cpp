@@ -56,6 +56,8 @@ Profiler::~Profiler() {
 }
 
 int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s) {
+    ctx->n_launch[FAM_CONV] += 1;
+    ctx->n_flops[FAM_CONV] += conv_gemm_flops(p);
     if (ctx->prof.on) {
         ctx->prof.begin(FAM_CONV, s);
         ctx->prof.flops[FAM_CONV] += conv_gemm_flops(p);
@@ -67,11 +69,26 @@ int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s) {
 }
 
 int run_skinny(ts_ctx *ctx, const SkinnyParams &p, hipStream_t s) {
+    ctx->n_launch[FAM_SKINNY] += 1;
+    ctx->n_flops[FAM_SKINNY] += 2.0 * p.M * (double)p.N * p.Ktot;
     if (ctx->prof.on) {
         ctx->prof.begin(FAM_SKINNY, s);
         ctx->prof.flops[FAM_SKINNY] += 2.0 * p.M * (double)p.N * p.Ktot;
     }
     hipError_t e = launch_skinny_gemm(p, s);
+    if (ctx->prof.on) ctx->prof.end(s);
+    if (e != hipSuccess) return fail(std::string("skinny_gemm launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int run_skinny2(ts_ctx *ctx, const SkinnyParams &p0, const SkinnyParams &p1, hipStream_t s) {
+    ctx->n_launch[FAM_SKINNY] += 1;
+    ctx->n_flops[FAM_SKINNY] += 2.0 * p0.M * (double)p0.N * p0.Ktot + 2.0 * p1.M * (double)p1.N * p1.Ktot;
+    if (ctx->prof.on) {
+        ctx->prof.begin(FAM_SKINNY, s);
+        ctx->prof.flops[FAM_SKINNY] += 2.0 * p0.M * (double)p0.N * p0.Ktot + 2.0 * p1.M * (double)p1.N * p1.Ktot;
+    }
+    hipError_t e = launch_skinny_gemm2(&p0, &p1, s);
     if (ctx->prof.on) ctx->prof.end(s);
     if (e != hipSuccess) return fail(std::string("skinny_gemm launch: ") + hipGetErrorString(e));
     return 0;
@@ -258,8 +275,18 @@ struct ts_convnet {   // encoder trunk: project, stack, down, stack, down, stack
     Stack s1, s2, s3;
     bool has_pre_vq = false;
     ConvLayer pre_vq;
-    Pool pool;
-    DevBuf xin;   // padded copy of the input when in_dim % 32 != 0
+    // scratch is per stream (one weight copy per GPU, one activation arena per stream): independent batches may be in
+    // flight on different streams of the same device
+    struct Work {
+        Pool pool;
+        DevBuf xin;   // padded copy of the input when in_dim % 32 != 0
+    };
+    std::map<hipStream_t, std::unique_ptr<Work>> works;
+    Work &work(hipStream_t s) {
+        auto &w = works[s];
+        if (!w) w.reset(new Work());
+        return *w;
+    }
 };
 
 namespace {
@@ -303,35 +330,40 @@ int run_stack(ts_ctx *ctx, const Stack &st, Pool &pool, int cur, int c, int B, i
     return 0;
 }
 
-// encoder trunk: x (B,T,in_dim) -> pool buffer holding (B,T/4,hid); returns buffer index and H
-int run_trunk(ts_convnet *n, const float *x, int B, int T, hipStream_t s, int *out_idx, int *H) {
+// encoder trunk: x (B,T,in_dim) with row stride x_ld (0 = in_dim) -> pool buffer holding (B,T/4,hid); returns buffer
+// index and H
+int run_trunk(ts_convnet *n, const float *x, int x_ld, int B, int T, hipStream_t s, int *out_idx, int *H) {
     if (T < 4) return fail("sequence too short: need T >= 4 frames");
     ts_ctx *ctx = n->ctx;
     const int hid = n->hid;
-    TS_TRY(n->pool.ensure((size_t)B * T * (hid / 4)));
+    ts_convnet::Work &wk = n->work(s);
+    Pool &pool = wk.pool;
+    TS_TRY(pool.ensure((size_t)B * T * (hid / 4)));
     const float *xin = x;
     int ldx = n->in_dim;
     if (n->in_dim % 32 != 0) {
         const int cp = n->project.cin_pad;
-        TS_TRY(n->xin.ensure((size_t)B * T * cp * sizeof(float)));
+        TS_TRY(wk.xin.ensure((size_t)B * T * cp * sizeof(float)));
         MiscScope ms(ctx, s);
-        TS_HIP(launch_pad_rows(x, n->in_dim, n->in_dim, n->xin.f(), cp, cp, (long)B * T, s));
-        xin = n->xin.f();
+        TS_HIP(launch_pad_rows(x, x_ld > 0 ? x_ld : n->in_dim, n->in_dim, wk.xin.f(), cp, cp, (long)B * T, s));
+        xin = wk.xin.f();
         ldx = cp;
+    } else if (x_ld > 0) {
+        ldx = x_ld;
     }
     int L = T, tmp = 0, cur = 0, o = 0;
-    TS_TRY(run_layer(ctx, n->project, xin, ldx, B, L, nullptr, 0, n->pool.buf(0), hid / 4, 0, hid / 4, s, &tmp));
-    TS_TRY(run_stack(ctx, n->s1, n->pool, cur, hid / 4, B, L, s, &o));
+    TS_TRY(run_layer(ctx, n->project, xin, ldx, B, L, nullptr, 0, pool.buf(0), hid / 4, 0, hid / 4, s, &tmp));
+    TS_TRY(run_stack(ctx, n->s1, pool, cur, hid / 4, B, L, s, &o));
     cur = o;
-    o = n->pool.pick(cur);
-    TS_TRY(run_layer(ctx, n->down1, n->pool.buf(cur), hid / 4, B, L, nullptr, 0, n->pool.buf(o), hid / 2, 0, hid / 2, s, &L));
+    o = pool.pick(cur);
+    TS_TRY(run_layer(ctx, n->down1, pool.buf(cur), hid / 4, B, L, nullptr, 0, pool.buf(o), hid / 2, 0, hid / 2, s, &L));
     cur = o;
-    TS_TRY(run_stack(ctx, n->s2, n->pool, cur, hid / 2, B, L, s, &o));
+    TS_TRY(run_stack(ctx, n->s2, pool, cur, hid / 2, B, L, s, &o));
     cur = o;
-    o = n->pool.pick(cur);
-    TS_TRY(run_layer(ctx, n->down2, n->pool.buf(cur), hid / 2, B, L, nullptr, 0, n->pool.buf(o), hid, 0, hid, s, &L));
+    o = pool.pick(cur);
+    TS_TRY(run_layer(ctx, n->down2, pool.buf(cur), hid / 2, B, L, nullptr, 0, pool.buf(o), hid, 0, hid, s, &L));
     cur = o;
-    TS_TRY(run_stack(ctx, n->s3, n->pool, cur, hid, B, L, s, &o));
+    TS_TRY(run_stack(ctx, n->s3, pool, cur, hid, B, L, s, &o));
     *out_idx = o;
     *H = L;
     return 0;
@@ -347,20 +379,29 @@ struct ts_vqvae {
     DevBuf aft_table;   // [ncode][hid] = aft_vq_conv(embedding row): Decoder's first layer as a gather table
     Stack d1, d2, d3;
     ConvLayer up2, up3, project;
-    Pool pool;
-    DevBuf z, lat;      // encoder output (B*H, emb), internal latents (B*H) int64
+    struct Work {
+        Pool pool;
+        DevBuf z, lat;   // encoder output (B*H, emb), internal latents (B*H) int64
+    };
+    std::map<hipStream_t, std::unique_ptr<Work>> works;
+    Work &work(hipStream_t s) {
+        auto &w = works[s];
+        if (!w) w.reset(new Work());
+        return *w;
+    }
 };
 
 namespace {
 
-int vq_encode_impl(ts_vqvae *vq, const float *poses, int B, int T, float *z_out, int64_t *lat_out, float *q_out,
-                   hipStream_t s, int *Hout) {
+int vq_encode_impl(ts_vqvae *vq, const float *poses, int poses_ld, int B, int T, float *z_out, int64_t *lat_out,
+                   float *q_out, hipStream_t s, int *Hout) {
     ts_ctx *ctx = vq->ctx;
     int idx = 0, H = 0, tmp = 0;
-    TS_TRY(run_trunk(&vq->enc, poses, B, T, s, &idx, &H));
-    TS_TRY(vq->z.ensure((size_t)B * H * vq->emb * sizeof(float)));
-    float *z = z_out ? z_out : vq->z.f();
-    TS_TRY(run_layer(ctx, vq->enc.pre_vq, vq->enc.pool.buf(idx), vq->hid, B, H, nullptr, 0, z, vq->emb, 0, vq->emb, s, &tmp));
+    TS_TRY(run_trunk(&vq->enc, poses, poses_ld, B, T, s, &idx, &H));
+    ts_vqvae::Work &wk = vq->work(s);
+    TS_TRY(wk.z.ensure((size_t)B * H * vq->emb * sizeof(float)));
+    float *z = z_out ? z_out : wk.z.f();
+    TS_TRY(run_layer(ctx, vq->enc.pre_vq, vq->enc.work(s).pool.buf(idx), vq->hid, B, H, nullptr, 0, z, vq->emb, 0, vq->emb, s, &tmp));
     {
         MiscScope ms(ctx, s);
         TS_HIP(launch_vq_argmin(z, vq->emb, B * H, vq->codebook.f(), vq->code_sq.f(), vq->ncode, vq->emb, lat_out, 1, s));
@@ -373,7 +414,7 @@ int vq_encode_impl(ts_vqvae *vq, const float *poses, int B, int T, float *z_out,
 int vq_decode_impl(ts_vqvae *vq, const int64_t *lat, int B, int H, float *out, int out_ld, int col0, hipStream_t s) {
     ts_ctx *ctx = vq->ctx;
     const int hid = vq->hid;
-    Pool &pool = vq->pool;
+    Pool &pool = vq->work(s).pool;
     TS_TRY(pool.ensure((size_t)B * H * hid));
     {
         MiscScope ms(ctx, s);
@@ -460,8 +501,8 @@ int ts_audioenc_forward(ts_convnet *net, const float *mfcc, int B, int T, float 
     if (!net || !mfcc || !feat) return fail("ts_audioenc_forward: null argument");
     hipStream_t s = (hipStream_t)stream;
     int idx = 0, H = 0;
-    TS_TRY(run_trunk(net, mfcc, B, T, s, &idx, &H));
-    TS_HIP(hipMemcpyAsync(feat, net->pool.buf(idx), (size_t)B * H * net->hid * sizeof(float), hipMemcpyDeviceToDevice, s));
+    TS_TRY(run_trunk(net, mfcc, 0, B, T, s, &idx, &H));
+    TS_HIP(hipMemcpyAsync(feat, net->work(s).pool.buf(idx), (size_t)B * H * net->hid * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
@@ -512,7 +553,7 @@ void ts_vqvae_destroy(ts_vqvae *vq) { delete vq; }
 int ts_vqvae_encode(ts_vqvae *vq, const float *poses, int B, int T, float *z, int64_t *lat, float *q, void *stream) {
     if (!vq || !poses || !lat) return fail("ts_vqvae_encode: null argument");
     int H = 0;
-    return vq_encode_impl(vq, poses, B, T, z, lat, q, (hipStream_t)stream, &H);
+    return vq_encode_impl(vq, poses, 0, B, T, z, lat, q, (hipStream_t)stream, &H);
 }
 
 int ts_vqvae_decode(ts_vqvae *vq, const int64_t *lat, int B, int H, float *out, int out_ld, int col0, void *stream) {
@@ -528,10 +569,11 @@ int ts_vqvae_forward(ts_vqvae *vq, const float *poses, int B, int T, int64_t *la
     int H = 0;
     int64_t *l = lat;
     if (!l) {
-        TS_TRY(vq->lat.ensure((size_t)B * (T / 4 + 1) * sizeof(int64_t)));
-        l = static_cast<int64_t *>(vq->lat.p);
+        ts_vqvae::Work &wk = vq->work(s);
+        TS_TRY(wk.lat.ensure((size_t)B * (T / 4 + 1) * sizeof(int64_t)));
+        l = static_cast<int64_t *>(wk.lat.p);
     }
-    TS_TRY(vq_encode_impl(vq, poses, B, T, nullptr, l, nullptr, s, &H));
+    TS_TRY(vq_encode_impl(vq, poses, 0, B, T, nullptr, l, nullptr, s, &H));
     return vq_decode_impl(vq, l, B, H, out, out_ld, col0, s);
 }
 
@@ -545,26 +587,12 @@ int ts_body_vq_infer(ts_vqvae *vb, ts_vqvae *vh, const float *poses, int B, int 
     const int off[2] = {0, db};
     for (int k = 0; k < 2; ++k) {
         ts_vqvae *vq = vqs[k];
-        // the trunk's first op pads/copies its input columns; give it a column-offset view
-        TS_TRY(vq->lat.ensure((size_t)B * (T / 4 + 1) * sizeof(int64_t)));
-        int64_t *l = static_cast<int64_t *>(vq->lat.p);
-        // copy the part's columns into the padded input buffer directly
-        ts_ctx *ctx = vq->ctx;
-        const int cp = vq->enc.project.cin_pad;
-        TS_TRY(vq->enc.xin.ensure((size_t)B * T * cp * sizeof(float)));
-        {
-            MiscScope ms(ctx, s);
-            TS_HIP(launch_pad_rows(poses + off[k], ld, vq->in_dim, vq->enc.xin.f(), cp, cp, (long)B * T, s));
-        }
-        // run the trunk on the already padded buffer
+        ts_vqvae::Work &wk = vq->work(s);
+        TS_TRY(wk.lat.ensure((size_t)B * (T / 4 + 1) * sizeof(int64_t)));
+        int64_t *l = static_cast<int64_t *>(wk.lat.p);
         int H = 0;
-        {
-            const int saved = vq->enc.in_dim;
-            vq->enc.in_dim = cp;   // multiple of 32: run_trunk then uses the buffer as is
-            int r = vq_encode_impl(vq, vq->enc.xin.f(), B, T, nullptr, l, nullptr, s, &H);
-            vq->enc.in_dim = saved;
-            if (r) return r;
-        }
+        // the part's columns are a strided view of the (B,T,129) rows: the trunk pads/copies them with row stride ld
+        TS_TRY(vq_encode_impl(vq, poses + off[k], ld, B, T, nullptr, l, nullptr, s, &H));
         TS_TRY(vq_decode_impl(vq, l, B, H, recon, ld, off[k], s));
         if (codes) {   // codes (B,H,2): column k
             TS_HIP(hipMemcpy2DAsync(codes + k, 2 * sizeof(int64_t), l, sizeof(int64_t), sizeof(int64_t), (size_t)B * H,

@@ -20,6 +20,8 @@
 //     fuse_h  (after layer 0) XH_1[j] = fusion_h[:, :D] . out_h_0 + AEH[r]
 //     head1/2 logits = output_conv(XH_NL[j]) ; sample -> codes[r][j]
 #include <algorithm>
+#include <cstdlib>
+#include <tuple>
 
 #include "host_common.h"
 
@@ -34,9 +36,33 @@ struct ts_pixelcnn {
     DevBuf fva, fha;                              // fusion_{v,h}[:, :D]  [D][D]
     ConvLayer aud_embed, aud_fv, aud_fh;          // embedding_aud ; fusion_{v,h}[:, D:] (+ fusion bias)
     DevBuf w1, b1, w2, b2;                        // output_conv
-    // work buffers (sized for the largest (B, Htot) seen)
-    int capB = 0, capH = 0;
-    DevBuf aud_all, AE, AEV, AEH, tok32, label32, XV, OV0, OVlast, HV, V2H, XH, G, OH0, Y, LG, tfcodes;
+    bool use_graph = true;
+    // Work set: every buffer the row loop touches + the hipGraph replays of it.  One per stream, so that independent
+    // batches can be in flight on different streams against the single weight copy above.
+    struct Work {
+        int capB = 0, capH = 0;
+        DevBuf aud_all, AE, AEV, AEH, tok32, label32, XV, OV0, OVlast, HV, V2H, XH, G, OH0, Y, LG, tfcodes;
+        // every pointer inside the captured kernels is one of the buffers above or the staging buffers below, so a graph
+        // is valid for any caller pointers; key = (B, H, H0, mode)
+        DevBuf codes_int, unif_int, dyn;
+        hipStream_t cap_stream = nullptr;
+        std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
+        std::map<std::tuple<int, int, int, int>, std::pair<long, double>> graph_stats;   // skinny launches, flops
+        void drop_graphs() {
+            for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
+            graphs.clear();
+        }
+        ~Work() {
+            drop_graphs();
+            if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        }
+    };
+    std::map<hipStream_t, std::unique_ptr<Work>> works;
+    Work &work(hipStream_t s) {
+        auto &w = works[s];
+        if (!w) w.reset(new Work());
+        return *w;
+    }
 };
 
 namespace {
@@ -46,29 +72,33 @@ int upload_vec(std::vector<std::unique_ptr<DevBuf>> &dst, const std::vector<floa
     return dst.back()->upload(v.data(), v.size() * sizeof(float));
 }
 
-int ensure_work(ts_pixelcnn *p, int B, int Htot) {
-    if (B <= p->capB && Htot <= p->capH) return 0;
-    const int cb = std::max(B, p->capB), ch = std::max(Htot, p->capH);
+int ensure_work(ts_pixelcnn *p, ts_pixelcnn::Work *w, int B, int Htot) {
+    if (B <= w->capB && Htot <= w->capH) return 0;
+    const int cb = std::max(B, w->capB), ch = std::max(Htot, w->capH);
     const size_t D = p->D, NL = p->NL, f = sizeof(float);
-    TS_TRY(p->aud_all.ensure((size_t)cb * ch * p->AD * f));
-    TS_TRY(p->AE.ensure((size_t)cb * ch * D * f));
-    TS_TRY(p->AEV.ensure((size_t)cb * ch * D * f));
-    TS_TRY(p->AEH.ensure((size_t)cb * ch * D * f));
-    TS_TRY(p->tok32.ensure((size_t)cb * ch * 2 * sizeof(int)));
-    TS_TRY(p->label32.ensure((size_t)cb * sizeof(int)));
-    TS_TRY(p->XV.ensure(NL * 2 * cb * 2 * D * f));
-    TS_TRY(p->OV0.ensure((size_t)cb * 2 * D * f));
-    TS_TRY(p->OVlast.ensure((size_t)cb * 2 * D * f));
-    TS_TRY(p->HV.ensure(NL * cb * 4 * D * f));
-    TS_TRY(p->V2H.ensure(NL * cb * 4 * D * f));
-    TS_TRY(p->XH.ensure((NL + 1) * 2 * cb * D * f));
-    TS_TRY(p->G.ensure((size_t)cb * D * f));
-    TS_TRY(p->OH0.ensure((size_t)cb * D * f));
-    TS_TRY(p->Y.ensure((size_t)cb * p->HID * f));
-    TS_TRY(p->LG.ensure((size_t)cb * p->V * f));
-    TS_TRY(p->tfcodes.ensure((size_t)cb * ch * 2 * sizeof(int64_t)));
-    p->capB = cb;
-    p->capH = ch;
+    TS_TRY(w->aud_all.ensure((size_t)cb * ch * p->AD * f));
+    TS_TRY(w->AE.ensure((size_t)cb * ch * D * f));
+    TS_TRY(w->AEV.ensure((size_t)cb * ch * D * f));
+    TS_TRY(w->AEH.ensure((size_t)cb * ch * D * f));
+    TS_TRY(w->tok32.ensure((size_t)cb * ch * 2 * sizeof(int)));
+    TS_TRY(w->label32.ensure((size_t)cb * sizeof(int)));
+    TS_TRY(w->XV.ensure(NL * 2 * cb * 2 * D * f));
+    TS_TRY(w->OV0.ensure((size_t)cb * 2 * D * f));
+    TS_TRY(w->OVlast.ensure((size_t)cb * 2 * D * f));
+    TS_TRY(w->HV.ensure(NL * cb * 4 * D * f));
+    TS_TRY(w->V2H.ensure(NL * cb * 4 * D * f));
+    TS_TRY(w->XH.ensure((NL + 1) * 2 * cb * D * f));
+    TS_TRY(w->G.ensure((size_t)cb * D * f));
+    TS_TRY(w->OH0.ensure((size_t)cb * D * f));
+    TS_TRY(w->Y.ensure((size_t)cb * p->HID * f));
+    TS_TRY(w->LG.ensure((size_t)cb * p->V * f));
+    TS_TRY(w->tfcodes.ensure((size_t)cb * ch * 2 * sizeof(int64_t)));
+    TS_TRY(w->codes_int.ensure((size_t)cb * ch * 2 * sizeof(int64_t)));
+    TS_TRY(w->unif_int.ensure((size_t)cb * ch * 2 * sizeof(float)));
+    TS_TRY(w->dyn.ensure(2 * sizeof(uint64_t)));
+    w->drop_graphs();   // buffers moved: captured pointers are stale
+    w->capB = cb;
+    w->capH = ch;
     return 0;
 }
 
@@ -79,6 +109,8 @@ struct RunCfg {
     int64_t clip0;
     int64_t *codes;     // (B,H,2)
     float *logits;      // (B,H,2,V) or null
+    const uint64_t *dyn;   // device {seed, clip0} (graph replay) or null
+    ts_pixelcnn::Work *w;
 };
 
 SkinnyParams base_params(int M, int N, int epi) {
@@ -110,17 +142,19 @@ void add_gather(SkinnyParams &q, const float *table, long stride, const int *gid
     q.Ktot += len;
 }
 
-// vertical stack + v->h projections of row r
+// vertical stack + v->h projections of row r.  Launch plan (NL + 2 launches): v0 | fuse_v + v2h_0 | v_1 |
+// v_2 + v2h_1 | ... | v_{NL-1} + v2h_{NL-2} | v2h_{NL-1}: vert_to_horiz of layer l-1 and the vertical conv of layer l
+// both depend only on layer l-1's output, so they share a launch (two independent problems, blockIdx.z).
 int vertical_row(ts_pixelcnn *p, const RunCfg &c, int r, hipStream_t s) {
     ts_ctx *ctx = p->ctx;
     const int B = c.B, D = p->D, NL = p->NL, Htot = c.Htot;
-    const int *tok = p->tok32.i();
-    const int *lab = p->label32.i();
-    auto XV = [&](int l, int par) { return p->XV.f() + ((size_t)(l * 2 + par) * B) * 2 * D; };
-    auto HV = [&](int l) { return p->HV.f() + (size_t)l * B * 4 * D; };
-    auto V2H = [&](int l) { return p->V2H.f() + (size_t)l * B * 4 * D; };
+    const int *tok = c.w->tok32.i();
+    const int *lab = c.w->label32.i();
+    auto XV = [&](int l, int par) { return c.w->XV.f() + ((size_t)(l * 2 + par) * B) * 2 * D; };
+    auto HV = [&](int l) { return c.w->HV.f() + (size_t)l * B * 4 * D; };
+    auto V2H = [&](int l) { return c.w->V2H.f() + (size_t)l * B * 4 * D; };
 
-    for (int l = 0; l < NL; ++l) {
+    auto make_v = [&](int l) {
         SkinnyParams q = base_params(B, 4 * D, EPI_GATE);
         if (l == 0) {
             for (int t = 0; t < 3; ++t) {
@@ -141,25 +175,25 @@ int vertical_row(ts_pixelcnn *p, const RunCfg &c, int r, hipStream_t s) {
         q.label = lab;
         q.cls_ld = 2 * D;
         q.gateD = D;
-        q.out = l == 0 ? p->OV0.f() : (l + 1 < NL ? XV(l + 1, r & 1) : p->OVlast.f());
+        q.out = l == 0 ? c.w->OV0.f() : (l + 1 < NL ? XV(l + 1, r & 1) : c.w->OVlast.f());
         q.out_stride = 2 * D;
         q.pre = HV(l);
         q.pre_stride = 4 * D;
-        TS_TRY(run_skinny(ctx, q, s));
-
-        if (l == 0 && NL > 1) {   // audio fusion in front of layer 1 (gated_pixelcnn_v2.py:137-144)
-            SkinnyParams f = base_params(2 * B, D, EPI_LINEAR);
-            add_dense(f, p->OV0.f(), D, 0, D);
-            f.W = p->fva.f();
-            f.ldw = D;
-            f.add1 = p->AEV.f() + (size_t)r * D;
-            f.add1_stride = (long)Htot * D;
-            f.add1_shift = 1;
-            f.out = XV(1, r & 1);
-            f.out_stride = D;
-            TS_TRY(run_skinny(ctx, f, s));
-        }
-        // vert_to_horiz on the pre-gate activations, both columns
+        return q;
+    };
+    auto make_fuse_v = [&]() {   // audio fusion in front of layer 1 (gated_pixelcnn_v2.py:137-144)
+        SkinnyParams f = base_params(2 * B, D, EPI_LINEAR);
+        add_dense(f, c.w->OV0.f(), D, 0, D);
+        f.W = p->fva.f();
+        f.ldw = D;
+        f.add1 = c.w->AEV.f() + (size_t)r * D;
+        f.add1_stride = (long)Htot * D;
+        f.add1_shift = 1;
+        f.out = XV(1, r & 1);
+        f.out_stride = D;
+        return f;
+    };
+    auto make_v2h = [&](int l) {   // vert_to_horiz on the pre-gate activations, both columns
         SkinnyParams v = base_params(2 * B, 2 * D, EPI_LINEAR);
         add_dense(v, HV(l), 2 * D, 0, 2 * D);
         v.W = p->wv2h[l]->f();
@@ -167,18 +201,24 @@ int vertical_row(ts_pixelcnn *p, const RunCfg &c, int r, hipStream_t s) {
         v.bias = p->bv2h[l]->f();
         v.out = V2H(l);
         v.out_stride = 2 * D;
-        TS_TRY(run_skinny(ctx, v, s));
-    }
-    return 0;
+        return v;
+    };
+
+    TS_TRY(run_skinny(ctx, make_v(0), s));
+    if (NL == 1) return run_skinny(ctx, make_v2h(0), s);
+    TS_TRY(run_skinny2(ctx, make_fuse_v(), make_v2h(0), s));
+    TS_TRY(run_skinny(ctx, make_v(1), s));
+    for (int l = 2; l < NL; ++l) TS_TRY(run_skinny2(ctx, make_v(l), make_v2h(l - 1), s));
+    return run_skinny(ctx, make_v2h(NL - 1), s);
 }
 
 // horizontal chain + head + sampler for position (r, j)
 int horizontal_pos(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s) {
     ts_ctx *ctx = p->ctx;
     const int B = c.B, D = p->D, NL = p->NL, Htot = c.Htot;
-    const int *tok = p->tok32.i();
-    auto V2H = [&](int l) { return p->V2H.f() + (size_t)l * B * 4 * D; };
-    auto XH = [&](int l, int col) { return p->XH.f() + ((size_t)(l * 2 + col) * B) * D; };
+    const int *tok = c.w->tok32.i();
+    auto V2H = [&](int l) { return c.w->V2H.f() + (size_t)l * B * 4 * D; };
+    auto XH = [&](int l, int col) { return c.w->XH.f() + ((size_t)(l * 2 + col) * B) * D; };
 
     for (int l = 0; l < NL; ++l) {
         SkinnyParams q = base_params(B, 2 * D, EPI_GATE);
@@ -198,20 +238,20 @@ int horizontal_pos(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s)
         q.add1 = V2H(l) + (size_t)j * 2 * D;
         q.add1_stride = 4 * D;
         q.cls = p->cls[l]->f();
-        q.label = p->label32.i();
+        q.label = c.w->label32.i();
         q.cls_ld = 2 * D;
         q.gateD = D;
-        q.out = p->G.f();
+        q.out = c.w->G.f();
         q.out_stride = D;
         TS_TRY(run_skinny(ctx, q, s));
 
         SkinnyParams h = base_params(B, D, EPI_LINEAR);
-        add_dense(h, p->G.f(), D, 0, D);
+        add_dense(h, c.w->G.f(), D, 0, D);
         h.W = p->wr[l]->f();
         h.ldw = D;
         h.bias = p->br[l]->f();
         if (l == 0) {
-            h.out = p->OH0.f();
+            h.out = c.w->OH0.f();
         } else {
             h.add1 = XH(l, j);
             h.add1_stride = D;
@@ -222,40 +262,40 @@ int horizontal_pos(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s)
 
         if (l == 0 && NL > 1) {
             SkinnyParams f = base_params(B, D, EPI_LINEAR);
-            add_dense(f, p->OH0.f(), D, 0, D);
+            add_dense(f, c.w->OH0.f(), D, 0, D);
             f.W = p->fha.f();
             f.ldw = D;
-            f.add1 = p->AEH.f() + (size_t)r * D;
+            f.add1 = c.w->AEH.f() + (size_t)r * D;
             f.add1_stride = (long)Htot * D;
             f.out = XH(1, j);
             f.out_stride = D;
             TS_TRY(run_skinny(ctx, f, s));
         }
     }
-    const float *xfin = NL > 1 ? XH(NL, j) : p->OH0.f();
+    const float *xfin = NL > 1 ? XH(NL, j) : c.w->OH0.f();
     SkinnyParams h1 = base_params(B, p->HID, EPI_LINEAR);
     add_dense(h1, xfin, D, 0, D);
     h1.W = p->w1.f();
     h1.ldw = D;
     h1.bias = p->b1.f();
     h1.relu = 1;
-    h1.out = p->Y.f();
+    h1.out = c.w->Y.f();
     h1.out_stride = p->HID;
     TS_TRY(run_skinny(ctx, h1, s));
 
     SkinnyParams h2 = base_params(B, p->V, EPI_LINEAR);
-    add_dense(h2, p->Y.f(), p->HID, 0, p->HID);
+    add_dense(h2, c.w->Y.f(), p->HID, 0, p->HID);
     h2.W = p->w2.f();
     h2.ldw = p->HID;
     h2.bias = p->b2.f();
-    h2.out = p->LG.f();
+    h2.out = c.w->LG.f();
     h2.out_stride = p->V;
     TS_TRY(run_skinny(ctx, h2, s));
 
     SampleParams sp;
     std::memset(&sp, 0, sizeof(sp));
     const int ro = r - c.H0;   // row in the caller's (B,H,2) arrays
-    sp.logits = p->LG.f();
+    sp.logits = c.w->LG.f();
     sp.B = B;
     sp.V = p->V;
     sp.mode = c.mode;
@@ -263,8 +303,9 @@ int horizontal_pos(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s)
     sp.u_stride = (long)c.H * 2;
     sp.seed = c.seed;
     sp.clip_index0 = c.clip0;
+    sp.dyn = c.dyn;
     sp.position = (uint32_t)(ro * 2 + j);
-    sp.tok32 = p->tok32.i() + (size_t)r * 2 + j;
+    sp.tok32 = c.w->tok32.i() + (size_t)r * 2 + j;
     sp.tok_stride = (long)Htot * 2;
     sp.codes = c.codes + (size_t)ro * 2 + j;
     sp.code_stride = (long)c.H * 2;
@@ -369,10 +410,22 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
     TS_TRY(p->b1.upload(b1, (size_t)p->HID * sizeof(float)));
     TS_TRY(p->w2.upload(w2, (size_t)V * p->HID * sizeof(float)));
     TS_TRY(p->b2.upload(b2, (size_t)V * sizeof(float)));
+    if (const char *e = std::getenv("TS_NO_GRAPH")) p->use_graph = !(e[0] && e[0] != '0');
     *out = p.release();
     return 0;
 }
 void ts_pixelcnn_destroy(ts_pixelcnn *p) { delete p; }
+
+int ts_pixelcnn_graph_stats(ts_pixelcnn *p, void *stream, int B, int H, int mode, int64_t *launches, double *flops) {
+    if (!p) return fail("ts_pixelcnn_graph_stats: null argument");
+    auto it = p->works.find((hipStream_t)stream);
+    if (it == p->works.end()) return fail("ts_pixelcnn_graph_stats: nothing was run on this stream");
+    auto jt = it->second->graph_stats.find(std::make_tuple(B, H, 0, mode));
+    if (jt == it->second->graph_stats.end()) return fail("ts_pixelcnn_graph_stats: no captured graph for this shape");
+    if (launches) *launches = jt->second.first;
+    if (flops) *flops = jt->second.second;
+    return 0;
+}
 
 int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud, int B, int H, int mode,
                          const float *uniforms, uint64_t seed, int64_t clip0, int64_t *codes, float *logits,
@@ -385,35 +438,44 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
     hipStream_t s = (hipStream_t)stream;
     ts_ctx *ctx = p->ctx;
     const int Htot = H0 + H, D = p->D, AD = p->AD;
-    TS_TRY(ensure_work(p, B, Htot));
+    ts_pixelcnn::Work *w = &p->work(s);
+    TS_TRY(ensure_work(p, w, B, Htot));
 
-    RunCfg c{B, H, H0, Htot, mode, uniforms, seed, clip0, codes, logits};
+    // The row loop is replayed from a hipGraph (host launch cost would otherwise dominate: ~100 dependent tiny
+    // launches per row); eager launches remain for the instrumented / logits-returning / teacher-forced paths.
+    const bool graph = p->use_graph && !ctx->prof.on && !logits && mode != TS_TEACHER_FORCED;
+    RunCfg c{B, H, H0, Htot, mode, uniforms, seed, clip0, codes, logits, nullptr, w};
+    if (graph) {
+        c.codes = static_cast<int64_t *>(w->codes_int.p);
+        c.uniforms = mode == TS_SAMPLE_UNIFORMS ? w->unif_int.f() : nullptr;
+        c.dyn = static_cast<const uint64_t *>(w->dyn.p);
+    }
 
     // ---- audio conditioning for every row: AE = embedding_aud(aud); AEV/AEH = fusion_{v,h}[:, D:] . AE + bias ----
     const float *aud_all = aud;
     if (H0 > 0) {
         const size_t f = sizeof(float);
-        TS_HIP(hipMemcpy2DAsync(p->aud_all.f(), (size_t)Htot * AD * f, pre_aud, (size_t)H0 * AD * f, (size_t)H0 * AD * f,
+        TS_HIP(hipMemcpy2DAsync(w->aud_all.f(), (size_t)Htot * AD * f, pre_aud, (size_t)H0 * AD * f, (size_t)H0 * AD * f,
                                 B, hipMemcpyDeviceToDevice, s));
-        TS_HIP(hipMemcpy2DAsync(p->aud_all.f() + (size_t)H0 * AD, (size_t)Htot * AD * f, aud, (size_t)H * AD * f,
+        TS_HIP(hipMemcpy2DAsync(w->aud_all.f() + (size_t)H0 * AD, (size_t)Htot * AD * f, aud, (size_t)H * AD * f,
                                 (size_t)H * AD * f, B, hipMemcpyDeviceToDevice, s));
-        aud_all = p->aud_all.f();
+        aud_all = w->aud_all.f();
     }
     {
         ConvParams q;
-        conv_layer_params(p->aud_embed, aud_all, AD, 1, B * Htot, nullptr, 0, p->AE.f(), D, 0, D, &q);
+        conv_layer_params(p->aud_embed, aud_all, AD, 1, B * Htot, nullptr, 0, w->AE.f(), D, 0, D, &q);
         TS_TRY(run_conv(ctx, q, 0, s));
-        conv_layer_params(p->aud_fv, p->AE.f(), D, 1, B * Htot, nullptr, 0, p->AEV.f(), D, 0, D, &q);
+        conv_layer_params(p->aud_fv, w->AE.f(), D, 1, B * Htot, nullptr, 0, w->AEV.f(), D, 0, D, &q);
         TS_TRY(run_conv(ctx, q, 0, s));
-        conv_layer_params(p->aud_fh, p->AE.f(), D, 1, B * Htot, nullptr, 0, p->AEH.f(), D, 0, D, &q);
+        conv_layer_params(p->aud_fh, w->AE.f(), D, 1, B * Htot, nullptr, 0, w->AEH.f(), D, 0, D, &q);
         TS_TRY(run_conv(ctx, q, 0, s));
     }
     {
         MiscScope ms(ctx, s);
-        TS_HIP(launch_i64_to_i32(label, p->label32.i(), B, s));
+        TS_HIP(launch_i64_to_i32(label, w->label32.i(), B, s));
         // known codes: the continuity prefix, and every position when teacher forced
         if (H0 > 0 || mode == TS_TEACHER_FORCED) {
-            int64_t *tf = static_cast<int64_t *>(p->tfcodes.p);
+            int64_t *tf = static_cast<int64_t *>(w->tfcodes.p);
             const size_t e = sizeof(int64_t);
             if (H0 > 0)
                 TS_HIP(hipMemcpy2DAsync(tf, (size_t)Htot * 2 * e, pre_codes, (size_t)H0 * 2 * e, (size_t)H0 * 2 * e, B,
@@ -421,16 +483,49 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
             if (mode == TS_TEACHER_FORCED)
                 TS_HIP(hipMemcpy2DAsync(tf + (size_t)H0 * 2, (size_t)Htot * 2 * e, codes, (size_t)H * 2 * e,
                                         (size_t)H * 2 * e, B, hipMemcpyDeviceToDevice, s));
-            TS_HIP(launch_i64_to_i32(tf, p->tok32.i(), (long)B * Htot * 2, s));
+            TS_HIP(launch_i64_to_i32(tf, w->tok32.i(), (long)B * Htot * 2, s));
         }
     }
 
-    for (int r = 0; r < Htot; ++r) {
-        TS_TRY(vertical_row(p, c, r, s));
-        if (r < H0) continue;                                         // prefix rows only feed the row cache
-        if (mode == TS_TEACHER_FORCED && !logits) continue;           // nothing to produce
-        for (int j = 0; j < 2; ++j) TS_TRY(horizontal_pos(p, c, r, j, s));
+    auto row_loop = [&](hipStream_t st) -> int {
+        for (int r = 0; r < Htot; ++r) {
+            TS_TRY(vertical_row(p, c, r, st));
+            if (r < H0) continue;                                         // prefix rows only feed the row cache
+            if (mode == TS_TEACHER_FORCED && !logits) continue;           // nothing to produce
+            for (int j = 0; j < 2; ++j) TS_TRY(horizontal_pos(p, c, r, j, st));
+        }
+        return 0;
+    };
+    if (!graph) return row_loop(s);
+
+    if (mode == TS_SAMPLE_UNIFORMS)
+        TS_HIP(hipMemcpyAsync(w->unif_int.p, uniforms, (size_t)B * H * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const uint64_t dynh[2] = {seed, (uint64_t)clip0};
+    TS_HIP(hipMemcpyAsync(w->dyn.p, dynh, sizeof(dynh), hipMemcpyHostToDevice, s));   // pageable: staged before return
+    const auto key = std::make_tuple(B, H, H0, mode);
+    auto it = w->graphs.find(key);
+    if (it == w->graphs.end()) {
+        if (!w->cap_stream) TS_HIP(hipStreamCreateWithFlags(&w->cap_stream, hipStreamNonBlocking));
+        hipGraph_t g = nullptr;
+        const long l0 = ctx->n_launch[FAM_SKINNY];
+        const double f0 = ctx->n_flops[FAM_SKINNY];
+        TS_HIP(hipStreamBeginCapture(w->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = row_loop(w->cap_stream);
+        w->graph_stats[key] = {ctx->n_launch[FAM_SKINNY] - l0, ctx->n_flops[FAM_SKINNY] - f0};
+        const hipError_t ec = hipStreamEndCapture(w->cap_stream, &g);
+        if (rc != 0) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        if (ec != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
+        hipGraphExec_t ex = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+        it = w->graphs.emplace(key, ex).first;
     }
+    TS_HIP(hipGraphLaunch(it->second, s));
+    TS_HIP(hipMemcpyAsync(codes, w->codes_int.p, (size_t)B * H * 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     return 0;
 }
 

@@ -221,10 +221,11 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
         if (p.mode == TS_SAMPLE_UNIFORMS) {
             u = p.uniforms[(long)b * p.u_stride];
         } else {
-            const uint64_t clip = (uint64_t)(p.clip_index0 + b);
+            const uint64_t seed = p.dyn ? p.dyn[0] : p.seed;
+            const uint64_t clip = (uint64_t)((p.dyn ? (int64_t)p.dyn[1] : p.clip_index0) + b);
             uint32_t r;
-            philox4x32_10(p.position, (uint32_t)clip, (uint32_t)(clip >> 32), 0u, (uint32_t)p.seed,
-                          (uint32_t)(p.seed >> 32), r);
+            philox4x32_10(p.position, (uint32_t)clip, (uint32_t)(clip >> 32), 0u, (uint32_t)seed,
+                          (uint32_t)(seed >> 32), r);
             u = (float)(r >> 8) * (1.0f / 16777216.0f);
         }
         const int chunk = (p.V + 255) / 256;
