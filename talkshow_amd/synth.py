@@ -135,6 +135,80 @@ def pixelcnn_state_dict(seed=0, input_dim=2048, dim=256, n_layers=15, n_classes=
     return b.sd
 
 
+def face_state_dict(seed=0, n_layers=12, hidden=768, heads=12, ffn=3072, conv_dim=512, num_classes=4,
+                    pos_k=128, pos_groups=16, legacy_weight_norm_keys=False):
+    """`s2g_face.Generator` (`nets/spg/s2g_face.py:142-224`) around the HF wav2vec2-base architecture
+    (`nets/spg/wav2vec.py:73-143`; key names of transformers >= 4.3x; `legacy_weight_norm_keys=True` emits the
+    4.22-era `weight_g` / `weight_v` names the reference's own checkpoints carry)."""
+    b = _Builder(seed, 707)
+    p = "audio_encoder."
+    b.normal(p + "masked_spec_embed", (hidden,), 0.5)
+    kern, = ((10, 3, 3, 3, 3, 2, 2),)
+    for i, k in enumerate(kern):
+        cin = 1 if i == 0 else conv_dim
+        b.normal(f"{p}feature_extractor.conv_layers.{i}.conv.weight", (conv_dim, cin, k), 1.5 / np.sqrt(cin * k))
+        if i == 0:
+            b.uniform(f"{p}feature_extractor.conv_layers.0.layer_norm.weight", (conv_dim,), 0.8, 1.2)
+            b.normal(f"{p}feature_extractor.conv_layers.0.layer_norm.bias", (conv_dim,), 0.1)
+
+    def ln(prefix, c):
+        b.uniform(prefix + ".weight", (c,), 0.8, 1.2)
+        b.normal(prefix + ".bias", (c,), 0.05)
+
+    def lin(prefix, cout, cin, gain=1.0):
+        b.normal(prefix + ".weight", (cout, cin), gain / np.sqrt(cin))
+        b.normal(prefix + ".bias", (cout,), 0.05)
+
+    ln(p + "feature_projection.layer_norm", conv_dim)
+    lin(p + "feature_projection.projection", hidden, conv_dim)
+    b.normal(p + "encoder.pos_conv_embed.conv.bias", (hidden,), 0.05)
+    g_key, v_key = (("weight_g", "weight_v") if legacy_weight_norm_keys
+                    else ("parametrizations.weight.original0", "parametrizations.weight.original1"))
+    b.uniform(p + "encoder.pos_conv_embed.conv." + g_key, (1, 1, pos_k), 1.0, 3.0)
+    b.normal(p + "encoder.pos_conv_embed.conv." + v_key, (hidden, hidden // pos_groups, pos_k), 1.0)
+    ln(p + "encoder.layer_norm", hidden)
+    for l in range(n_layers):
+        q = f"{p}encoder.layers.{l}."
+        for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            lin(q + "attention." + nm, hidden, hidden, 1.3 if nm in ("q_proj", "k_proj") else 1.0)
+        ln(q + "layer_norm", hidden)
+        lin(q + "feed_forward.intermediate_dense", ffn, hidden, 1.2)
+        lin(q + "feed_forward.output_dense", hidden, ffn, 1.2)
+        ln(q + "final_layer_norm", hidden)
+    lin("audio_feature_map", 256, hidden)
+    b.normal("audio_middle.id_mlp.weight", (64, num_classes, 1), 0.7)
+    b.normal("audio_middle.id_mlp.bias", (64,), 0.1)
+
+    def conv(prefix, cout, cin, k, gain=1.3):
+        b.normal(prefix + ".weight", (cout, cin, k), gain / np.sqrt(cin * k))
+        b.normal(prefix + ".bias", (cout,), 0.05)
+
+    fn = "audio_middle.first_net.conv_layers."
+    conv(fn + "0.residual_layer.0", 256, 320, 3, 0.8)
+    conv(fn + "0.conv", 256, 320, 3)
+    ln(fn + "0.norm", 256)
+    for i in (1, 2):
+        conv(fn + f"{i}.conv", 256, 256, 3)
+        ln(fn + f"{i}.norm", 256)
+    # nn.GRU present in checkpoints, unused by forward (s2g_face.py:121,134)
+    b.normal("audio_middle.grus.weight_ih_l0", (768, 256), 0.05)
+    b.normal("audio_middle.grus.weight_hh_l0", (768, 256), 0.05)
+    b.normal("audio_middle.grus.bias_ih_l0", (768,), 0.05)
+    b.normal("audio_middle.grus.bias_hh_l0", (768,), 0.05)
+    for d, (c0, c) in enumerate(((256, 64), (256, 256))):
+        for i in range(3):
+            conv(f"decoder.{d}.{i}.conv", c, c0 if i == 0 else c, 3)
+            ln(f"decoder.{d}.{i}.norm", c)
+    conv("final_out.0", 3, 64, 1, 0.3)
+    conv("final_out.1", 100, 256, 1, 0.3)
+    return b.sd
+
+
+def wav16(seed, B, N, scale=0.1):
+    """(B, N) float32 synthetic 16 kHz waveform."""
+    return (_rng(seed, 606).standard_normal((B, N)) * scale).astype(F32)
+
+
 # --- synthetic inputs (SURVEY.md §8(d)) -------------------------------------------------------
 
 def mfcc_features(seed, B, T, scale=20.0):

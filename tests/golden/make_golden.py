@@ -234,6 +234,27 @@ def main():
             save("body_vq_e2e_full", poses129=p129, out=out, codes=np.stack([lat_b.numpy(), lat_h.numpy()], -1),
                  c_index=np.asarray(c_index_3d))
 
+    # ---- 5. face generator over the installed transformers wav2vec2 (reference: s2g_face.Generator + wav2vec.py) ----
+    if want("face_full"):
+        fcfg = json.load(open(os.path.join(REF, "config/face.json")))
+        from trainer.config import Object
+        fconfig = Object(fcfg)
+        targs = argparse.Namespace(gpu="cpu", infer=True)
+        w = quiet(nets.s2g_face, targs, fconfig)
+        fsd = synth.face_state_dict(seed=7)
+        w.load_state_dict({"generator": T(fsd)})            # TrainWrapperBaseClass.load_state_dict, strict
+        B, N = 2, 32000                                      # 2 s of 16 kHz audio -> 60 frames
+        wav = synth.wav16(31, B, N)
+        frame = N * 30 // 16000
+        w.generator.eval()
+        with torch.no_grad():
+            ids = torch.zeros(B, 4); ids[1, 2] = 1.0         # the all-zero id of smplx_face.py:206 and a one-hot
+            out = w.generator(torch.from_numpy(wav)[:, None, :], None, ids, time_steps=frame)[0]
+            hs = w.generator.audio_encoder(torch.from_numpy(wav), frame_num=frame).last_hidden_state
+            gen = w.generate(torch.from_numpy(wav)[:, None, :], frame)      # smplx_face.py:221-238 (zero id)
+        print("face_full: out", tuple(out.shape), "std", float(out.std()), "hidden std", float(hs.std()))
+        save("face_full", wav=wav, ids=ids.numpy(), out=out.numpy(), hidden=hs.numpy(), generate_zero_id=gen.numpy())
+
     meta_path = os.path.join(HERE, "golden_meta.json")
     old = json.load(open(meta_path)) if os.path.exists(meta_path) else {"cases": {}}
     old["cases"].update(meta["cases"])
