@@ -30,6 +30,7 @@ typedef struct ts_ctx ts_ctx;
 typedef struct ts_convnet ts_convnet;     /* AudioEncoder            nets/spg/vqvae_1d.py:11-34          */
 typedef struct ts_vqvae ts_vqvae;         /* VQVAE                   nets/spg/vqvae_1d.py:152-208        */
 typedef struct ts_pixelcnn ts_pixelcnn;   /* GatedPixelCNN           nets/spg/gated_pixelcnn_v2.py:90-177 */
+typedef struct ts_face ts_face;           /* s2g_face.Generator      nets/spg/s2g_face.py:142-224        */
 
 /* One entry of a reference state_dict: key name as the reference spells it (an optional "module." prefix is
  * accepted and stripped, nets/smplx_body_pixel.py:119-126), fp32 host data, shape.  int64 buffers
@@ -106,6 +107,19 @@ int ts_pixelcnn_generate(ts_pixelcnn *pix, const int64_t *label_dev, const float
 /* Launch count and algorithmic flops (2*M*N*K over every skinny_gemm launch) of the hipGraph captured for
  * (B, H, mode) on `stream` — what one replay executes; used by bench.py for the roofline line. */
 int ts_pixelcnn_graph_stats(ts_pixelcnn *pix, void *stream, int B, int H, int mode, int64_t *launches, double *flops);
+
+/* ---- s2g_face.Generator over the wav2vec2-base encoder (nets/spg/s2g_face.py:142-224, nets/spg/wav2vec.py:73-143) ---- */
+/* state_dict of the reference Generator (keys "audio_encoder.*", "audio_feature_map.*", "audio_middle.*", "decoder.*",
+ * "final_out.*"; the positional conv's weight norm is accepted under both the transformers>=4.3x names
+ * "...conv.parametrizations.weight.original0/1" and the 4.22-era "...conv.weight_g/_v"). */
+int ts_face_create(ts_ctx *ctx, const ts_tensor *sd, int n, int n_layers, int num_classes, ts_face **out);
+void ts_face_destroy(ts_face *face);
+/* Generator.forward, eval (s2g_face.py:196-224; TrainWrapper.generate / infer_on_audio, smplx_face.py:169-238):
+ * wav_dev (B,N) fp32 16 kHz samples, id_dev (B,num_classes) fp32 one-hot or all-zero (smplx_face.py:205-208),
+ * frames = N*30//16000 normally -> out_dev (B,frames,103) = [jaw(3) | expression(100)];
+ * hidden_dev optional (B,frames,768): the wav2vec2 last_hidden_state (parity tests). */
+int ts_face_generate(ts_face *face, const float *wav_dev, int B, int N, int frames, const float *id_dev, float *out_dev,
+                     float *hidden_dev, void *stream);
 
 /* ---- whole wrappers --------------------------------------------------------------------------------------- */
 /* s2g_body_pixel.TrainWrapper.infer_on_audio after the MFCC front-end (smplx_body_pixel.py:272-285):

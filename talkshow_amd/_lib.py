@@ -41,6 +41,9 @@ SIGNATURES = {
     "ts_pixelcnn_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ts_pixelcnn_destroy": (None, [_vp]),
     "ts_pixelcnn_generate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ts_face_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, C.POINTER(_vp)]),
+    "ts_face_destroy": (None, [_vp]),
+    "ts_face_generate": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ts_pixelcnn_graph_stats": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "ts_body_pixel_infer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _u64, _i64, _vp, _vp, _vp]),
     "ts_body_vq_infer": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -39,7 +39,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_LD];
 
-    const ConvGroup &g = p.g[blockIdx.z];
+    const ConvGroup &g = p.g[p.zdiv > 0 ? 0 : blockIdx.z];
+    const float *gx = g.x, *gw = g.w, *gbias = g.bias, *gres = g.res;
+    float *gout = g.out;
+    if (p.zdiv > 0) {   // batched problems: shift every pointer by this problem's offsets
+        const int z0 = blockIdx.z / p.zdiv, z1 = blockIdx.z - z0 * p.zdiv;
+        gx += z0 * p.x_zs0 + z1 * p.x_zs1;
+        gw += z0 * p.w_zs0 + z1 * p.w_zs1;
+        gout += z0 * p.o_zs0 + z1 * p.o_zs1;
+        if (gbias) gbias += z1 * p.b_zs1;
+        if (gres) gres += z0 * p.r_zs0 + z1 * p.r_zs1;
+    }
+    const long ldw = p.ldw > 0 ? p.ldw : p.Ktot;
+    const int w_rows = p.w_rows > 0 ? p.w_rows : 0x7fffffff;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -61,23 +73,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             a_t[i] = 0;
         }
     }
-    const float *wbase = g.w + (long)(n0 + lrow) * p.Ktot + lc4;
+    const float *wbase = gw + (long)(n0 + lrow) * ldw + lc4;
 
     f32x4 ra[PA], rb[PB];
-    auto load_chunk = [&](int s, int cc, int kofs) {
-        const int d = g.seg[s].d;
+    auto load_chunk = [&](int s, int tap, int cc, int kofs) {
+        const int d = g.seg[s].d + tap;
         const int coff = g.seg[s].c0 + cc * BK + lc4;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             int it = a_t[i] + d;
             if (a_rowbase[i] >= 0 && it >= 0 && it < p.Lin)
-                ra[i] = *reinterpret_cast<const f32x4 *>(g.x + (a_rowbase[i] + it) * p.ldx + coff);
+                ra[i] = *reinterpret_cast<const f32x4 *>(gx + (a_rowbase[i] + it) * p.ldx + coff);
             else
                 ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int i = 0; i < PB; ++i)
-            rb[i] = *reinterpret_cast<const f32x4 *>(wbase + (long)i * 32 * p.Ktot + kofs);
+        for (int i = 0; i < PB; ++i) {
+            if (n0 + i * 32 + lrow < w_rows) rb[i] = *reinterpret_cast<const f32x4 *>(wbase + (long)i * 32 * ldw + kofs);
+            else rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
@@ -97,8 +111,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const int li = lane & 31, lh = lane >> 5;
 
     // ---- K loop over (segment, 32-channel chunk), software pipelined ----
-    int s = 0, cc = 0, kofs = 0;
-    load_chunk(s, cc, kofs);
+    int s = 0, tap = 0, cc = 0, kofs = 0;
+    load_chunk(s, tap, cc, kofs);
     store_chunk(0);
     __syncthreads();
     int buf = 0;
@@ -108,8 +122,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         bool has_next = it + 1 < nchunks;
         if (has_next) {
             kofs += BK;
-            if (++cc * BK >= g.seg[s].len) { cc = 0; ++s; }
-            load_chunk(s, cc, kofs);
+            if (++cc * BK >= g.seg[s].len) {
+                cc = 0;
+                if (++tap >= g.seg[s].ntap) { tap = 0; ++s; }
+            }
+            load_chunk(s, tap, cc, kofs);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -137,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + li;
-        const float bv = g.bias ? g.bias[n] : 0.f;
+        const float bv = gbias ? gbias[n] : 0.f;
         const bool nok = n < p.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -146,10 +163,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (nok && m < p.M) {
                     float v = acc[i][j][r] + bv;
-                    if (g.res) v += g.res[(long)m * p.ldr + n];
+                    if (gres && !p.res_after_act) v += gres[(long)m * p.ldr + n];
                     if (p.act == 1) v = v >= 0.f ? v : v * 0.2f;
                     else if (p.act == 2) v = v > 0.f ? v : 0.f;
-                    g.out[(long)m * p.ldo + g.out_col0 + n] = v;
+                    else if (p.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (gres && p.res_after_act) v += gres[(long)m * p.ldr + n];
+                    gout[(long)m * p.ldo + g.out_col0 + n] = v;
                 }
             }
         }
@@ -157,6 +176,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 }
 
 double conv_gemm_flops(const ConvParams &p) { return 2.0 * p.M * (double)p.N * p.Ktot * p.ngroups; }
+
 
 static int pick_tile(const ConvParams &p) {
     // Prefer the large tile when it alone fills the chip; otherwise smaller tiles so that the tile count is

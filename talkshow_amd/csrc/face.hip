@@ -1,0 +1,266 @@
+// Kernels of the face generator that are not GEMM-shaped (everything GEMM-shaped runs on conv_gemm_f32):
+//   w2v_conv0_*      wav2vec2 feature-extractor layer 0: Conv1d(1,512,k10,s5,no bias) + GroupNorm(512,512) + GELU
+//                    (HF Wav2Vec2GroupNormConvLayer; called at nets/spg/wav2vec.py:92).  Bandwidth bound: the conv is
+//                    recomputed in the apply pass (10 MAC/output) instead of storing the 32k-frame pre-norm tensor.
+//   lerp_ln          linear_interpolation 50->30 fps (nets/spg/wav2vec.py:64-70) fused with the feature-projection
+//                    LayerNorm(512) (HF Wav2Vec2FeatureProjection; :107)
+//   layernorm_rows   nn.LayerNorm over channels (+ post-norm residual, ReLU): encoder LNs and nets/layers.py:142-151
+//   softmax_rows     softmax(QK^T * d^-0.5) of HF eager_attention_forward
+//   transpose_v      V^T per (clip, head) so that P.V is an NT GEMM
+//   fill_id          id_mlp(one-hot id) broadcast over time and concatenated (nets/spg/s2g_face.py:127-130)
+#include "kernels.h"
+
+namespace ts {
+
+constexpr int C0_TB = 128;   // output frames per block in the conv0 kernels
+
+__device__ inline float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// partial sums of conv0 output per (clip, time block, channel): grid (tblocks, B), 256 threads x 2 channels
+__global__ __launch_bounds__(256) void w2v_conv0_stats_kernel(const float *__restrict__ wav, int N, int L0,
+                                                              const float *__restrict__ w, double2 *__restrict__ part,
+                                                              int C) {
+    __shared__ float sw[C0_TB * 5 + 16];
+    const int b = blockIdx.y, tb = blockIdx.x, t0 = tb * C0_TB;
+    const int nt = min(C0_TB, L0 - t0);
+    for (int i = threadIdx.x; i < nt * 5 + 5; i += 256) {
+        const int idx = t0 * 5 + i;
+        sw[i] = idx < N ? wav[(long)b * N + idx] : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float wk[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) wk[k] = w[c * 10 + k];
+        double s = 0.0, s2 = 0.0;
+        for (int t = 0; t < nt; ++t) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) v = fmaf(wk[k], sw[t * 5 + k], v);
+            s += v;
+            s2 += (double)v * v;
+        }
+        part[((long)b * gridDim.x + tb) * C + c] = double2{s, s2};
+    }
+}
+
+// fixed-order reduction over the time blocks -> (mean, rstd) per (clip, channel)
+__global__ void w2v_gn_finalize_kernel(const double2 *__restrict__ part, int ntb, int C, int L0, float2 *__restrict__ stats,
+                                       int BC) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    const int b = i / C, c = i - b * C;
+    double s = 0.0, s2 = 0.0;
+    for (int t = 0; t < ntb; ++t) {
+        const double2 v = part[((long)b * ntb + t) * C + c];
+        s += v.x;
+        s2 += v.y;
+    }
+    const double mean = s / L0;
+    double var = s2 / L0 - mean * mean;
+    if (var < 0) var = 0;
+    stats[i] = float2{(float)mean, (float)(1.0 / sqrt(var + 1e-5))};
+}
+
+// recompute conv0, normalise, GELU, store NLC (B, L0, C)
+__global__ __launch_bounds__(256) void w2v_conv0_apply_kernel(const float *__restrict__ wav, int N, int L0,
+                                                              const float *__restrict__ w, const float2 *__restrict__ stats,
+                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                              float *__restrict__ out, int C) {
+    __shared__ float sw[C0_TB * 5 + 16];
+    const int b = blockIdx.y, t0 = blockIdx.x * C0_TB;
+    const int nt = min(C0_TB, L0 - t0);
+    for (int i = threadIdx.x; i < nt * 5 + 5; i += 256) {
+        const int idx = t0 * 5 + i;
+        sw[i] = idx < N ? wav[(long)b * N + idx] : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float wk[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) wk[k] = w[c * 10 + k];
+        const float2 st = stats[b * C + c];
+        const float g = gamma[c], be = beta[c];
+        for (int t = 0; t < nt; ++t) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) v = fmaf(wk[k], sw[t * 5 + k], v);
+            v = (v - st.x) * st.y * g + be;
+            out[((long)b * L0 + t0 + t) * C + c] = gelu_erf(v);
+        }
+    }
+}
+
+hipError_t launch_w2v_conv0(const float *wav, int B, int N, int L0, const float *w, const float *gamma, const float *beta,
+                            double2 *part, float2 *stats, float *out, int C, hipStream_t s) {
+    const int ntb = (L0 + C0_TB - 1) / C0_TB;
+    hipLaunchKernelGGL(w2v_conv0_stats_kernel, dim3(ntb, B), dim3(256), 0, s, wav, N, L0, w, part, C);
+    hipLaunchKernelGGL(w2v_gn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, part, ntb, C, L0, stats, B * C);
+    hipLaunchKernelGGL(w2v_conv0_apply_kernel, dim3(ntb, B), dim3(256), 0, s, wav, N, L0, w, stats, gamma, beta, out, C);
+    return hipGetLastError();
+}
+
+// ---- row-wise LayerNorm: one wavefront per row, C = 64 * CPL -----------------------------------------------------
+template <int CPL>
+__device__ inline void ln_row(float (&v)[CPL], const float *gamma, const float *beta, int lane, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) s += v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * (1.0f / (64 * CPL));
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / (64 * CPL)) + eps);
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) v[i] = (v[i] - mean) * rstd * gamma[lane + 64 * i] + beta[lane + 64 * i];
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float *__restrict__ x, int ldx, long M,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             const float *__restrict__ post_res, int ldr, int relu,
+                                                             float *__restrict__ out, int ldo) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    float v[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) v[i] = x[m * ldx + lane + 64 * i];
+    ln_row<CPL>(v, gamma, beta, lane, 1e-5f);
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        float y = v[i];
+        if (post_res) y += post_res[m * ldr + lane + 64 * i];
+        if (relu) y = y > 0.f ? y : 0.f;
+        out[m * ldo + lane + 64 * i] = y;
+    }
+}
+
+hipError_t launch_layernorm_rows(const float *x, int ldx, long M, int C, const float *gamma, const float *beta,
+                                 const float *post_res, int ldr, int relu, float *out, int ldo, hipStream_t s) {
+    dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    switch (C) {
+        case 64: hipLaunchKernelGGL(layernorm_rows_kernel<1>, grid, block, 0, s, x, ldx, M, gamma, beta, post_res, ldr, relu, out, ldo); break;
+        case 256: hipLaunchKernelGGL(layernorm_rows_kernel<4>, grid, block, 0, s, x, ldx, M, gamma, beta, post_res, ldr, relu, out, ldo); break;
+        case 512: hipLaunchKernelGGL(layernorm_rows_kernel<8>, grid, block, 0, s, x, ldx, M, gamma, beta, post_res, ldr, relu, out, ldo); break;
+        case 768: hipLaunchKernelGGL(layernorm_rows_kernel<12>, grid, block, 0, s, x, ldx, M, gamma, beta, post_res, ldr, relu, out, ldo); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---- time interpolation (align_corners=False) + LayerNorm(512) --------------------------------------------------
+__global__ __launch_bounds__(256) void lerp_ln_kernel(const float *__restrict__ x, int Lin, int T, long M,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                      float *__restrict__ out) {
+    constexpr int CPL = 8, C = 512;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int b = (int)(m / T), j = (int)(m - (long)b * T);
+    const float scale = (float)Lin / (float)T;
+    float src = scale * ((float)j + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    const int i0 = (int)floorf(src);
+    const int i1 = min(i0 + 1, Lin - 1);
+    const float l1 = src - (float)i0, l0 = 1.0f - l1;
+    const float *r0 = x + ((long)b * Lin + i0) * C, *r1 = x + ((long)b * Lin + i1) * C;
+    float v[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) v[i] = r0[lane + 64 * i] * l0 + r1[lane + 64 * i] * l1;
+    ln_row<CPL>(v, gamma, beta, lane, 1e-5f);
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) out[m * C + lane + 64 * i] = v[i];
+}
+hipError_t launch_lerp_ln(const float *x, int B, int Lin, int T, const float *gamma, const float *beta, float *out,
+                          hipStream_t s) {
+    const long M = (long)B * T;
+    hipLaunchKernelGGL(lerp_ln_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, Lin, T, M, gamma, beta, out);
+    return hipGetLastError();
+}
+
+// ---- softmax over the first S columns of each row (scaled), zero the padding columns ---------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ p, long rows, int S, int ld, float scale) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float *r = p + m * ld;
+    float v[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < S ? r[c] * scale : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = (lane + 64 * i) < S ? expf(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < ld) r[c] = v[i] * inv;
+    }
+}
+hipError_t launch_softmax_rows(float *p, long rows, int S, int ld, float scale, hipStream_t s) {
+    if (ld > 512 || S > ld) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p, rows, S, ld, scale);
+    return hipGetLastError();
+}
+
+// ---- V^T: vt[z][d][t] = qkv[b][t][v_col0 + h*64 + d], zero for t >= T ; z = b*heads + h ------------------------
+__global__ __launch_bounds__(256) void transpose_v_kernel(const float *__restrict__ qkv, int T, int ldq, int v_col0, int heads,
+                                                          float *__restrict__ vt, int Tp) {
+    __shared__ float tile[64][65];
+    const int z = blockIdx.y, b = z / heads, h = z - b * heads;
+    const int t0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int t = t0 + i;
+        tile[i][tx] = t < T ? qkv[((long)b * T + t) * ldq + v_col0 + h * 64 + tx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int t = t0 + tx;
+        if (t < Tp) vt[((long)z * 64 + i) * Tp + t] = tile[tx][i];
+    }
+}
+hipError_t launch_transpose_v(const float *qkv, int B, int T, int ldq, int v_col0, int heads, float *vt, int Tp,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(transpose_v_kernel, dim3((Tp + 63) / 64, B * heads), dim3(256), 0, s, qkv, T, ldq, v_col0, heads, vt, Tp);
+    return hipGetLastError();
+}
+
+// ---- id channels: x[b][t][col0 + j] = bias[j] + sum_c W[j][c] * id[b][c] ----------------------------------------
+__global__ void fill_id_kernel(const float *__restrict__ id, int nc, const float *__restrict__ w, const float *__restrict__ bias,
+                               int nj, float *__restrict__ x, int ld, int col0, long rows, int T) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nj) return;
+    const long m = i / nj;
+    const int j = (int)(i - m * nj);
+    const int b = (int)(m / T);
+    float v = bias[j];
+    for (int c = 0; c < nc; ++c) v = fmaf(w[j * nc + c], id[b * nc + c], v);
+    x[m * ld + col0 + j] = v;
+}
+hipError_t launch_fill_id(const float *id, int nc, const float *w, const float *bias, int nj, float *x, int ld, int col0,
+                          int B, int T, hipStream_t s) {
+    const long n = (long)B * T * nj;
+    hipLaunchKernelGGL(fill_id_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, id, nc, w, bias, nj, x, ld, col0,
+                       (long)B * T, T);
+    return hipGetLastError();
+}
+
+}  // namespace ts

@@ -166,6 +166,9 @@ int pack_conv_layer(const StateDict &sd, const std::string &conv_key, const std:
 // generic: pack an (N,K) row-major matrix (+bias) as a k1 ConvLayer (used for the PixelCNN audio precompute)
 int pack_linear_layer(const float *w, long ldw, const float *bias, int N, int K, ConvLayer *out);
 
+// raw form: w (cout, cin, K) reference layout, optional bias; taps[k] = input row shift of kernel index k
+int pack_conv_raw(const float *w, const float *bias, int cout, int cin, int K, const int *taps, int act, ConvLayer *out);
+
 // Fills ConvParams for `layer` applied to x (B, Lin, ldx) -> out; returns Lout (rows per clip of the output buffer).
 // For kind 2 the output buffer has 2*Lin rows of cout_pad (or ldo) floats.
 int conv_layer_params(const ConvLayer &layer, const float *x, int ldx, int B, int Lin, const float *res, int ldr,

@@ -14,9 +14,10 @@ namespace ts {
 // segments back to back (Ktot floats, K-contiguous), BatchNorm already folded in.
 // ------------------------------------------------------------------------------------------------
 struct ConvSeg {
-    int d;    // input row shift
+    int d;    // input row shift of the first tap
     int c0;   // first input channel
-    int len;  // channels in this segment (multiple of 32)
+    int len;  // channels per tap (multiple of 32)
+    int ntap; // consecutive taps d, d+1, ... sharing c0/len (0 or 1 = a single tap); K of the segment = ntap*len
 };
 
 struct ConvGroup {
@@ -35,9 +36,17 @@ struct ConvParams {
     int ldx, ldo, ldr;
     int N;     // columns stored per group (weights/bias are padded to a multiple of 128 rows)
     int Ktot;
-    int act;   // 0 none, 1 LeakyReLU(0.2), 2 ReLU
+    int act;   // 0 none, 1 LeakyReLU(0.2), 2 ReLU, 3 GELU (erf)
     int ngroups;
     ConvGroup g[4];
+    // optional extras (0 = off)
+    int res_after_act;   // residual is added after the activation instead of before it
+    long ldw;            // weight row stride in floats (0 = Ktot, packed)
+    int w_rows;          // number of valid weight rows (0 = padded to the grid); rows beyond read as zero
+    // batched mode (zdiv > 0): blockIdx.z = z0*zdiv + z1 indexes independent problems that share g[0]'s geometry;
+    // pointers advance by z0*zs0 + z1*zs1 floats
+    int zdiv;
+    long x_zs0, x_zs1, w_zs0, w_zs1, o_zs0, o_zs1, b_zs1, r_zs0, r_zs1;
 };
 
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128 (for tuning / tests)
@@ -131,5 +140,19 @@ struct SampleParams {
     long copy_stride;
 };
 hipError_t launch_sample(const SampleParams &p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// face generator kernels (face.hip)
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_w2v_conv0(const float *wav, int B, int N, int L0, const float *w, const float *gamma, const float *beta,
+                            double2 *part, float2 *stats, float *out, int C, hipStream_t s);
+hipError_t launch_layernorm_rows(const float *x, int ldx, long M, int C, const float *gamma, const float *beta,
+                                 const float *post_res, int ldr, int relu, float *out, int ldo, hipStream_t s);
+hipError_t launch_lerp_ln(const float *x, int B, int Lin, int T, const float *gamma, const float *beta, float *out,
+                          hipStream_t s);
+hipError_t launch_softmax_rows(float *p, long rows, int S, int ld, float scale, hipStream_t s);
+hipError_t launch_transpose_v(const float *qkv, int B, int T, int ldq, int v_col0, int heads, float *vt, int Tp, hipStream_t s);
+hipError_t launch_fill_id(const float *id, int nc, const float *w, const float *bias, int nj, float *x, int ld, int col0,
+                          int B, int T, hipStream_t s);
 
 }  // namespace ts

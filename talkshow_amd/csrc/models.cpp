@@ -172,6 +172,32 @@ int pack_conv_layer(const StateDict &sd, const std::string &conv_key, const std:
     return 0;
 }
 
+int pack_conv_raw(const float *w, const float *bias, int cout, int cin, int K, const int *taps, int act, ConvLayer *L) {
+    if (K > 4) return fail("pack_conv_raw: at most 4 taps");
+    L->kind = 0;
+    L->cin = cin;
+    L->cin_pad = round_up(cin, 32);
+    L->cout = cout;
+    L->cout_pad = round_up(cout, 32);
+    L->npad = round_up(cout, 128);
+    L->act = act;
+    L->ngroups = 1;
+    L->nseg = K;
+    const int cp = L->cin_pad;
+    L->ktot = K * cp;
+    std::vector<float> wp((size_t)L->npad * L->ktot, 0.f), bp(L->npad, 0.f);
+    for (int s = 0; s < K; ++s) {
+        L->segs[0][s] = ConvSeg{taps[s], 0, cp, 1};
+        for (int o = 0; o < cout; ++o)
+            for (int i = 0; i < cin; ++i) wp[(size_t)o * L->ktot + (size_t)s * cp + i] = w[((size_t)o * cin + i) * K + s];
+    }
+    if (bias)
+        for (int o = 0; o < cout; ++o) bp[o] = bias[o];
+    TS_TRY(L->w.upload(wp.data(), wp.size() * sizeof(float)));
+    TS_TRY(L->bias.upload(bp.data(), bp.size() * sizeof(float)));
+    return 0;
+}
+
 int pack_linear_layer(const float *w, long ldw, const float *bias, int N, int K, ConvLayer *L) {
     L->kind = 0;
     L->cin = K;

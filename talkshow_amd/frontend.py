@@ -37,3 +37,28 @@ def get_mfcc_sepa(aud_fn, sr=22000, fps=30):
     feat = get_mfcc_ta(aud_fn, sr=sr, fps=fps)
     gap = 2 * fps
     return feat, gap
+
+
+def get_wav16(aud_fn):
+    """Face front-end: `get_mfcc_ta(..., encoder_choice='faceformer')` = `librosa.load(aud_fn, sr=16000)` reshaped to
+    (N, 1), no normalisation (`data_utils/utils.py:194-198`).  Accepted: arrays / tensors of samples, `.npy`, and PCM or
+    float `.wav` files that are ALREADY at 16 kHz (mono = mean of channels, int PCM scaled to [-1, 1) as librosa does);
+    other sample rates need the resampler of the next scope row and raise."""
+    if isinstance(aud_fn, torch.Tensor):
+        x = aud_fn.detach().cpu().numpy()
+    elif isinstance(aud_fn, np.ndarray):
+        x = aud_fn
+    elif str(aud_fn).endswith(".npy"):
+        x = np.load(aud_fn)
+    elif str(aud_fn).endswith(".wav"):
+        from scipy.io import wavfile
+        sr, x = wavfile.read(aud_fn)
+        if sr != 16000:
+            raise NotImplementedError(f"{aud_fn}: sample rate {sr} != 16000; resampling is the next scope row (SURVEY.md §8f-1)")
+        if np.issubdtype(x.dtype, np.integer):
+            x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
+        if x.ndim == 2:
+            x = x.mean(axis=1)
+    else:
+        raise NotImplementedError(f"audio front-end: cannot read {aud_fn!r}")
+    return np.asarray(x, dtype=np.float32).reshape(-1, 1)

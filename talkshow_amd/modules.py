@@ -288,3 +288,54 @@ class GatedPixelCNN(NativeModule):
         rows = aud[..., 0].transpose(1, 2)
         _, logits = self.run(label, rows, mode=_lib.TS_TEACHER_FORCED, codes=x, want_logits=True)
         return logits.permute(0, 3, 1, 2)
+
+
+class FaceGenerator(NativeModule):
+    """`s2g_face.Generator(n_poses, each_dim, dim_list, training, device, identity, num_classes)` (`s2g_face.py:142-224`)."""
+
+    def __init__(self, n_poses=88, each_dim=None, dim_list=None, training=False, device=None, identity=True,
+                 num_classes=4, n_layers=12):
+        if not identity:
+            raise NotImplementedError("identity=False (convert_to_6d) is not used by any shipped config")
+        self.num_classes, self.n_layers = num_classes, n_layers
+        self.device = device
+        super().__init__(synth.face_state_dict(0, n_layers=n_layers, num_classes=num_classes))
+
+    def load_state_dict(self, sd, strict=True):
+        # checkpoints written with transformers 4.22 (the reference's pin) spell the weight-normed positional conv
+        # `weight_g` / `weight_v` (SURVEY.md §0.9)
+        ren = {"audio_encoder.encoder.pos_conv_embed.conv.weight_g":
+               "audio_encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original0",
+               "audio_encoder.encoder.pos_conv_embed.conv.weight_v":
+               "audio_encoder.encoder.pos_conv_embed.conv.parametrizations.weight.original1"}
+        sd = OrderedDict((ren.get(k.replace("module.", ""), k.replace("module.", "")), v) for k, v in sd.items())
+        return super().load_state_dict(sd, strict)
+
+    def _create(self, ctx):
+        arr, n, keep = _lib.pack_state_dict(self._sd)
+        h = C.c_void_p()
+        _lib.check(_lib.load().ts_face_create(ctx, arr, n, self.n_layers, self.num_classes, C.byref(h)))
+        return h
+
+    def _destroy(self, h):
+        _lib.load().ts_face_destroy(h)
+
+    def run(self, wav, id_vec, frames, want_hidden=False):
+        """wav (B,N) device fp32, id_vec (B,num_classes) -> (B,frames,103) [, hidden (B,frames,768)]."""
+        dev = self._dev()
+        wav = _dev_f32(wav, dev)
+        B, N = wav.shape
+        id_vec = _dev_f32(id_vec, dev).reshape(-1, self.num_classes)
+        if id_vec.shape[0] == 1 and B > 1:
+            id_vec = id_vec.repeat(B, 1).contiguous()
+        out = torch.empty((B, frames, 103), dtype=torch.float32, device=dev)
+        hid = torch.empty((B, frames, 768), dtype=torch.float32, device=dev) if want_hidden else None
+        _lib.check(_lib.load().ts_face_generate(self.handle(), _lib.dptr(wav), B, N, int(frames), _lib.dptr(id_vec),
+                                                _lib.dptr(out), _lib.dptr(hid), _lib.stream_ptr()))
+        return (out, hid) if want_hidden else out
+
+    def __call__(self, in_spec, gt_poses=None, id=None, pre_state=None, time_steps=None):
+        """reference call shape (`s2g_face.py:196`): in_spec (B,1,N) -> (out (B,time_steps,103), None)."""
+        wav = _dev_f32(in_spec, self._dev())
+        wav = wav.reshape(wav.shape[0], -1)
+        return self.run(wav, id, time_steps), None

@@ -300,3 +300,42 @@ def test_full_size_properties(hip, tmp_path):
     # weights is idempotence of decode: same codes -> same poses, and decode is per-clip.
     body = w.g_body.decode_nlc(c1[..., 0].contiguous())
     np.testing.assert_array_equal(body.cpu().numpy(), p1[..., :39].cpu().numpy())
+
+
+# ----------------------------------------------------------------------------------------------- face generator
+def test_face_golden(hip, golden):
+    """wav2vec2 encoder + LN conv heads vs the reference goldens (transformers module run by make_golden.py)."""
+    from talkshow_amd.modules import FaceGenerator
+    g = golden("face_full")
+    m = FaceGenerator().cuda()
+    m.load_state_dict(synth.to_torch(synth.face_state_dict(seed=7)))
+    frame = g["out"].shape[1]
+    out, hid = m.run(g["wav"], g["ids"], frame, want_hidden=True)
+    np.testing.assert_allclose(hid.cpu().numpy(), g["hidden"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], atol=1e-4, rtol=0)      # 1e-4 on jaw / expression floats
+    # reference call shape: (B,1,N) in, tuple out; legacy weight-norm key names load to the same result
+    m2 = FaceGenerator().cuda()
+    sd = synth.to_torch(synth.face_state_dict(seed=7, legacy_weight_norm_keys=True))
+    m2.load_state_dict({"module." + k: v for k, v in sd.items()})
+    out2, none = m2(torch.from_numpy(g["wav"])[:, None, :], None, torch.from_numpy(g["ids"]), time_steps=frame)
+    assert none is None
+    np.testing.assert_array_equal(out2.cpu().numpy(), out.cpu().numpy())
+
+
+def test_wrapper_face(hip, golden, tmp_path):
+    from nets.init_model import init_model
+    from oracle import face_oracle as FO
+    g = golden("face_full")
+    args = argparse.Namespace(gpu=0, infer=True)
+    w = init_model("s2g_face", args, _config(tmp_path, "face"))
+    w.load_state_dict({"generator": synth.to_torch(synth.face_state_dict(seed=7))})
+    gen = w.generate(torch.from_numpy(g["wav"])[:, None, :], g["out"].shape[1])
+    np.testing.assert_allclose(gen.cpu().numpy(), g["generate_zero_id"], atol=1e-4, rtol=0)
+    # infer_on_audio on raw samples of one clip with a speaker id; vs the oracle (edge: odd sample count, ragged frames)
+    wav = synth.wav16(77, 1, 21337)
+    out = w.infer_on_audio(wav[0], id=torch.tensor([3]))
+    frame = 21337 * 30 // 16000
+    assert out.shape == (1, frame, 103)
+    ref = FO.face_generator(wav, np.eye(4, dtype=np.float32)[[3]], synth.face_state_dict(seed=7), frame)
+    np.testing.assert_allclose(out, ref, atol=1e-4, rtol=0)
+    assert w.each_dim == [3, 72, 90, 100]

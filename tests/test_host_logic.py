@@ -107,7 +107,7 @@ def test_body_vq_wrapper_surface(tmp_path):
 
 def test_out_of_scope_names_say_so():
     import nets
-    for cls in (nets.s2g_body_ae, nets.LS3DCG, nets.s2g_face):
+    for cls in (nets.s2g_body_ae, nets.LS3DCG):
         with pytest.raises(NotImplementedError):
             cls(None, None)
 
