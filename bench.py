@@ -70,6 +70,40 @@ def cpu_baseline(sds, seed):
 
 
 
+def face_block(local):
+    """BASELINE configs[2] as extra information: face generator, batch 64 x 10 s @16 kHz -> (64,300,103), fp32."""
+    from talkshow_amd import _lib, synth
+    from talkshow_amd.modules import FaceGenerator
+    lib = _lib.load()
+    ctx = _lib.context(local)
+    m = FaceGenerator().cuda()
+    m.load_state_dict(synth.to_torch(synth.face_state_dict(seed=0)))
+    B, N, T = 64, 160000, 300
+    wav = torch.from_numpy(synth.wav16(3000, B, N)).cuda()
+    ids = torch.nn.functional.one_hot(torch.arange(B) % 4, 4).float().cuda()
+    m.run(wav, ids, T)
+    torch.cuda.synchronize()
+    n0, f0 = (C.c_int64 * 3)(), (C.c_double * 3)()
+    t0 = time.perf_counter()
+    K = 3
+    for _ in range(K):
+        m.run(wav, ids, T)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    # instrumented pass: HIP event pairs around every launch
+    _lib.check(lib.ts_prof_enable(ctx, 1))
+    m.run(wav, ids, T)
+    torch.cuda.synchronize()
+    msf, nf, flf = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
+    _lib.check(lib.ts_prof_read(ctx, msf, nf, flf, 1))
+    _lib.check(lib.ts_prof_enable(ctx, 0))
+    ach = flf[0] / (msf[0] * 1e-3) / 1e12
+    return {"workload": "BASELINE configs[2]: face generator, batch=64 x 10 s @16 kHz, 103 params @30 fps",
+            "frames_per_s": B * T / dt, "ms_per_batch": dt * 1e3,
+            "conv_gemm_f32": {"launches": nf[0], "ms": msf[0], "achieved_TFLOPs": ach, "frac_of_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS},
+            "other_kernels_ms": msf[2]}
+
+
 def roofline_block(w, lib, _lib, stream, mfcc, ids, B, H, local, step):
     """Roofline of the dominant kernel + per-family breakdown.
 
@@ -131,6 +165,7 @@ def main():
                     help="independent steps (batches of 32 clips) in flight at once, one HIP stream each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-face", action="store_true")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,6 +255,11 @@ def main():
 
     if rank == 0 and not a.no_roofline:
         out.update(roofline_block(w, lib, _lib, streams[0], mfcc[0], ids, B, H, local, step))
+    if rank == 0 and not a.no_face:
+        try:
+            out["face"] = face_block(local)
+        except Exception as e:                       # the face line is extra information; never lose the main line
+            out["face"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sds, 1000)
     if rank == 0:

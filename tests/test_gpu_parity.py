@@ -339,3 +339,22 @@ def test_wrapper_face(hip, golden, tmp_path):
     ref = FO.face_generator(wav, np.eye(4, dtype=np.float32)[[3]], synth.face_state_dict(seed=7), frame)
     np.testing.assert_allclose(out, ref, atol=1e-4, rtol=0)
     assert w.each_dim == [3, 72, 90, 100]
+
+
+def test_face_full_length_vs_oracle(hip):
+    """A full 10 s clip (160 000 samples -> 499 conv frames -> 300 output frames) against the CPU oracle, plus batch
+    independence and run-to-run determinism at B=3."""
+    from oracle import face_oracle as FO
+    from talkshow_amd.modules import FaceGenerator
+    sd = synth.face_state_dict(seed=5)
+    m = FaceGenerator().cuda()
+    m.load_state_dict(synth.to_torch(sd))
+    wav = synth.wav16(41, 3, 160000)
+    ids = np.eye(4, dtype=np.float32)[[1, 0, 3]]
+    out = m.run(wav, ids, 300)
+    out2 = m.run(wav, ids, 300)
+    assert torch.equal(out, out2) and torch.isfinite(out).all()
+    solo = m.run(wav[1:2], ids[1:2], 300)
+    assert torch.equal(solo[0], out[1])
+    ref = FO.face_generator(wav[:1], ids[:1], sd, 300)
+    np.testing.assert_allclose(out[:1].cpu().numpy(), ref, atol=1e-4, rtol=0)
