@@ -327,9 +327,13 @@ hipError_t launch_skinny_gemm2(const SkinnyParams *p0, const SkinnyParams *p1, h
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    // split K so that each wave runs ~32 k (16 MFMAs): short critical path, all loads issued up front
-    if (Q >= 64) hipLaunchKernelGGL(skinny_gemm_kernel<16>, grid, dim3(1024), 0, stream, b);
-    else if (Q >= 32) hipLaunchKernelGGL(skinny_gemm_kernel<8>, grid, dim3(512), 0, stream, b);
+    // K is split over the waves of the workgroup; more waves = more loads in flight (lower latency for ONE chain) but a
+    // fatter workgroup (fewer independent chains fit on the chip at once).  TS_SKINNY_MAXW caps it (tuning).
+    static const int maxw = [] { const char *e = getenv("TS_SKINNY_MAXW"); return e ? atoi(e) : 16; }();
+    int W = Q >= 64 ? 16 : (Q >= 32 ? 8 : 4);
+    if (W > maxw) W = maxw;
+    if (W >= 16) hipLaunchKernelGGL(skinny_gemm_kernel<16>, grid, dim3(1024), 0, stream, b);
+    else if (W >= 8) hipLaunchKernelGGL(skinny_gemm_kernel<8>, grid, dim3(512), 0, stream, b);
     else hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, dim3(256), 0, stream, b);
     return hipGetLastError();
 }

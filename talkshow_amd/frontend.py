@@ -1,31 +1,154 @@
-"""Audio front-end boundary (`data_utils/utils.py:148-231`, `get_mfcc_ta` / `get_mfcc_sepa`).
+"""Audio front-end boundary (`data_utils/utils.py:148-263`: `get_mfcc_ta` / `get_mfcc_sepa`).
 
-The reference computes 64-d MFCCs with torchaudio on the CPU before the hot path starts ("next"
-row f1).  Until the on-device front-end lands, `aud_fn` may be
+In the reference this runs on the CPU before the hot path starts: `torchaudio.load` -> `Resample(sr_0 -> 22 kHz)` ->
+mono -> `torchaudio.transforms.MFCC(n_mfcc=64, n_fft=2048, n_mels=256, hop=734|1467, mel_scale='htk')` for the body, and
+`librosa.load(sr=16000)` raw samples for the face.  torchaudio / librosa are third-party code that is NOT under
+/root/reference and not installed in the target image, so this module restates their published algorithms in
+numpy/scipy on the host (same place in the pipeline as the reference's CPU front-end; it is not part of the HIP hot
+path and no kernel parity claim depends on it):
 
-  * a `(T, 64)` float array / tensor of MFCC features (what `get_mfcc_ta` returns), or
-  * a path to a `.npy` file holding such an array;
+  * Resample: torchaudio's `sinc_interp_hann` polyphase kernel (lowpass_filter_width=6, rolloff=0.99, ratio reduced
+    by gcd), applied per channel BEFORE the mono mean (`utils.py:150-154`);
+  * MFCC: periodic Hann window of n_fft, `center=True` reflect padding, power spectrum, HTK mel filterbank
+    (f_min 0, f_max sr/2, norm None), `10*log10(clamp(x, 1e-10))`, clamp at (per-clip max - 80 dB), orthonormal
+    DCT-II (256 -> 64).
 
-a `.wav` path raises with this explanation (torchaudio / librosa are not available in the target image).
+PARITY UNPINNED: neither library is available here to generate golden vectors, and the reference ships none
+(SURVEY.md §8c); tests/test_frontend.py checks the restatement against an independent float64 evaluation of the same
+formulae and against closed-form cases.  Everything downstream (the hot path) is pinned on feature arrays, which is
+also what `aud_fn` may be directly: a `(T, 64)` float array / tensor, or a `.npy` file of one.
 """
+import math
 import os
 
 import numpy as np
 import torch
 
+F32 = np.float32
+
+
+def load_wav(path):
+    """`torchaudio.load`: float32 in [-1, 1), shape (channels, N), native sample rate (PCM / float .wav files)."""
+    from scipy.io import wavfile
+    sr, x = wavfile.read(path)
+    if np.issubdtype(x.dtype, np.integer):
+        if x.dtype == np.uint8:
+            x = (x.astype(F32) - 128.0) / 128.0
+        else:
+            x = x.astype(F32) / float(np.iinfo(x.dtype).max + 1)
+    x = np.asarray(x, dtype=F32)
+    if x.ndim == 1:
+        x = x[None, :]
+    else:
+        x = np.ascontiguousarray(x.T)
+    return x, int(sr)
+
+
+def resample_sinc_hann(x, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """torchaudio.transforms.Resample (default `sinc_interp_hann`): x (C, N) -> (C, ceil(new*N/orig)) float32."""
+    if orig_freq == new_freq:
+        return x
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(orig, new) * rolloff
+    width = int(math.ceil(lowpass_filter_width * orig / base_freq))
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = (np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx) * base_freq
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base_freq / orig
+    kern = np.where(t == 0, 1.0, np.sin(t) / np.where(t == 0, 1.0, t)) * window * scale        # (new, 2*width+orig)
+    kern = kern.astype(F32)
+    C, N = x.shape
+    xp = np.pad(x, ((0, 0), (width, width + orig)))
+    nwin = (xp.shape[1] - kern.shape[1]) // orig + 1
+    win = np.lib.stride_tricks.sliding_window_view(xp, kern.shape[1], axis=1)[:, ::orig][:, :nwin]   # (C, nwin, K)
+    y = np.einsum("cwk,nk->cwn", win, kern, optimize=True).reshape(C, -1)                          # phases interleave
+    target = int(math.ceil(new * N / orig))
+    return np.ascontiguousarray(y[:, :target], dtype=F32)
+
+
+def _hz_to_mel_htk(f):
+    return 2595.0 * np.log10(1.0 + f / 700.0)
+
+
+def _mel_to_hz_htk(m):
+    return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+
+
+def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk'): (n_freqs, n_mels) triangular filters."""
+    all_freqs = np.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = np.linspace(_hz_to_mel_htk(f_min), _hz_to_mel_htk(f_max), n_mels + 2)
+    f_pts = _mel_to_hz_htk(m_pts)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return np.maximum(0.0, np.minimum(down, up)).astype(F32)
+
+
+def create_dct(n_mfcc, n_mels):
+    """torchaudio.functional.create_dct(norm='ortho'): (n_mels, n_mfcc) DCT-II matrix."""
+    n = np.arange(n_mels, dtype=np.float64)
+    k = np.arange(n_mfcc, dtype=np.float64)[:, None]
+    dct = np.cos(math.pi / n_mels * (n + 0.5) * k)
+    dct[0] *= 1.0 / math.sqrt(2.0)
+    dct *= math.sqrt(2.0 / n_mels)
+    return dct.T.astype(F32)
+
+
+def mfcc(wave, sample_rate, n_mfcc=64, n_fft=2048, hop_length=734, n_mels=256, top_db=80.0):
+    """torchaudio.transforms.MFCC(sample_rate, n_mfcc, melkwargs={n_fft, n_mels, hop_length, mel_scale='htk'}) on a
+    mono waveform (N,) -> (n_mfcc, T) with T = N // hop + 1 (`center=True`)."""
+    from scipy import fft as sfft
+    x = np.pad(np.asarray(wave, dtype=F32), (n_fft // 2, n_fft // 2), mode="reflect")
+    T = 1 + (x.shape[0] - n_fft) // hop_length
+    frames = np.lib.stride_tricks.sliding_window_view(x, n_fft)[::hop_length][:T]
+    window = (0.5 - 0.5 * np.cos(2.0 * math.pi * np.arange(n_fft) / n_fft)).astype(F32)          # periodic Hann
+    spec = sfft.rfft(frames * window[None, :], axis=1)                                             # float32 -> complex64
+    power = (spec.real.astype(F32) ** 2 + spec.imag.astype(F32) ** 2).astype(F32)                 # (T, 1025)
+    mel = power @ melscale_fbanks(n_fft // 2 + 1, 0.0, float(sample_rate // 2), n_mels, sample_rate)   # (T, n_mels)
+    db = (10.0 * np.log10(np.maximum(mel, F32(1e-10)))).astype(F32)                                # ref = 1 -> no offset
+    db = np.maximum(db, db.max() - F32(top_db))                                                    # per-clip max
+    return np.ascontiguousarray((db @ create_dct(n_mfcc, n_mels)).T, dtype=F32)
+
+
+def _hop(fps):
+    if fps == 15:
+        return 1467
+    if fps == 30:
+        return 734
+    raise ValueError(f"fps must be 15 or 30 (data_utils/utils.py:157-160), got {fps}")
+
+
+def _features_from_any(aud_fn):
+    if isinstance(aud_fn, torch.Tensor):
+        return aud_fn.detach().cpu().numpy()
+    if isinstance(aud_fn, np.ndarray):
+        return aud_fn
+    if isinstance(aud_fn, (str, os.PathLike)) and str(aud_fn).endswith(".npy"):
+        return np.load(aud_fn)
+    return None
+
+
+def _load_mono_resampled(aud_fn, sr):
+    audio, sr_0 = load_wav(aud_fn)
+    if sr != sr_0:
+        audio = resample_sinc_hann(audio, sr_0, sr)
+    if audio.shape[0] > 1:
+        audio = audio.mean(axis=0, keepdims=True, dtype=F32)
+    return audio[0]
+
 
 def get_mfcc_ta(aud_fn, sr=22000, fps=30, smlpx=True, type='mfcc', am=None, am_sr=None, encoder_choice='mfcc'):
-    if isinstance(aud_fn, torch.Tensor):
-        feat = aud_fn.detach().cpu().numpy()
-    elif isinstance(aud_fn, np.ndarray):
-        feat = aud_fn
-    elif isinstance(aud_fn, (str, os.PathLike)) and str(aud_fn).endswith(".npy"):
-        feat = np.load(aud_fn)
-    else:
-        raise NotImplementedError(
-            f"audio front-end: cannot turn {aud_fn!r} into MFCC features here. The wav -> 22 kHz -> MFCC(64) front-end "
-            "(torchaudio in the reference, data_utils/utils.py:148-231) is the next scope row (SURVEY.md §8f-1); pass the "
-            "(T, 64) MFCC array, or a .npy file of it, as `aud_fn`.")
+    """`get_mfcc_ta` (`utils.py:148-231`), body branch: -> (T, 64) float32 features."""
+    feat = _features_from_any(aud_fn)
+    if feat is None:
+        if type != 'mfcc':
+            raise NotImplementedError("only type='mfcc' is on the inference path")
+        feat = mfcc(_load_mono_resampled(aud_fn, sr), sr, hop_length=_hop(fps)).T
     feat = np.asarray(feat, dtype=np.float32)
     if feat.ndim != 2 or feat.shape[1] != 64:
         raise ValueError(f"MFCC features must have shape (T, 64), got {feat.shape}")
@@ -33,10 +156,15 @@ def get_mfcc_ta(aud_fn, sr=22000, fps=30, smlpx=True, type='mfcc', am=None, am_s
 
 
 def get_mfcc_sepa(aud_fn, sr=22000, fps=30):
-    """`data_utils/utils.py:234-263`: features plus the frame index of the 2 s split used by continuity mode."""
-    feat = get_mfcc_ta(aud_fn, sr=sr, fps=fps)
-    gap = 2 * fps
-    return feat, gap
+    """`get_mfcc_sepa` (`utils.py:234-263`): MFCCs of the first 2 s and of the rest, concatenated, + the split frame."""
+    feat = _features_from_any(aud_fn)
+    if feat is not None:
+        feat = np.asarray(feat, dtype=np.float32)
+        return feat, 2 * fps + 1
+    wave = _load_mono_resampled(aud_fn, sr)
+    f0 = mfcc(wave[:sr * 2], sr, hop_length=_hop(fps)).T
+    f1 = mfcc(wave[sr * 2:], sr, hop_length=_hop(fps)).T
+    return np.concatenate((f0, f1), axis=0), f0.shape[0]
 
 
 def get_wav16(aud_fn):

@@ -89,8 +89,8 @@ def test_init_model_surface(tmp_path):
     with pytest.raises(AssertionError):
         argsT = argparse.Namespace(gpu="cpu", infer=False)
         init_model("s2g_body_pixel", argsT, _config(tmp_path, "body_pixel")).infer_on_audio(np.zeros((60, 64), np.float32))
-    with pytest.raises(NotImplementedError):
-        w.infer_on_audio("some.wav", id=torch.tensor([0]))
+    with pytest.raises(FileNotFoundError):          # wav paths go through the host front-end now
+        w.infer_on_audio("no_such_file.wav", id=torch.tensor([0]))
 
 
 def test_body_vq_wrapper_surface(tmp_path):
