@@ -190,7 +190,7 @@ int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int de
     if (!ctx || !us_out) return fail("ts_debug_skinny_chain: null argument");
     const int N = gate ? 2 * K : K;
     DevBuf w, bias, x0, x1, lab, cls;
-    std::vector<float> hw((size_t)N * K), hb(N, 0.01f), hx((size_t)M * K, 0.5f), hc((size_t)4 * N, 0.01f);
+    std::vector<float> hw((size_t)N * K), hb(N, 0.01f), hx((size_t)M * K, 0.5f), hc((size_t)M * N, 0.01f);
     for (size_t i = 0; i < hw.size(); ++i) hw[i] = ((int)(i * 2654435761u >> 16) % 2001 - 1000) * (1.0f / (1000.f * K));
     std::vector<int> hl(M, 1);
     TS_TRY(w.upload(hw.data(), hw.size() * 4));
@@ -219,12 +219,10 @@ int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int de
         q.bias = bias.f();
         q.epi = gate ? EPI_GATE : EPI_LINEAR;
         q.gateD = K;
-        q.cls = gate ? cls.f() : nullptr;
-        q.label = lab.i();
+        q.clsrow = gate ? cls.f() : nullptr;
         q.cls_ld = N;
         q.out = (i & 1) ? x0.f() : x1.f();
         q.out_stride = K;
-        q.debug = debug;
         TS_HIP(launch_skinny_gemm(q, s));
     }
     TS_HIP(hipStreamEndCapture(s, &g));

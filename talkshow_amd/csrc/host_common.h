@@ -135,7 +135,7 @@ namespace ts {
 
 int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s);
 int run_skinny(ts_ctx *ctx, const SkinnyParams &p, hipStream_t s);
-int run_skinny2(ts_ctx *ctx, const SkinnyParams &p0, const SkinnyParams &p1, hipStream_t s);
+int run_skinny_batch(ts_ctx *ctx, const SkinnyParams *const *ps, int n, hipStream_t s);
 // misc launches are wrapped with this scope guard so they show up under FAM_MISC
 struct MiscScope {
     ts_ctx *ctx;

@@ -61,7 +61,7 @@ double conv_gemm_flops(const ConvParams &p);
 // conditioning and the tanh*sigmoid gate.
 // ------------------------------------------------------------------------------------------------
 struct SkinnySeg {
-    const float *base;   // dense: row m at base + (m >> row_shift) * row_stride (+ col offset baked in base)
+    const float *base;   // dense: row m at base + (m >> row_shift) * row_stride (+ col offset baked in base); null = zero rows
     const int *gidx;     // gather: row = base + gidx[m * gidx_stride] * row_stride ; negative index -> zero row
     long row_stride;
     long gidx_stride;
@@ -70,11 +70,13 @@ struct SkinnySeg {
 };
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1 };
+constexpr int SKINNY_MAX_SEG = 3;
+constexpr int SKINNY_MAX_PROBLEMS = 4;
 
 struct SkinnyParams {
     int M, N;            // N = number of weight rows (EPI_GATE: 2*gateD per group)
     int nseg, Ktot;
-    SkinnySeg seg[6];
+    SkinnySeg seg[SKINNY_MAX_SEG];
     const float *W;      // weight row n at W + n*ldw (K-contiguous, Ktot floats used)
     long ldw;
     const float *bias;   // [N] or null
@@ -84,27 +86,25 @@ struct SkinnyParams {
     const float *add2;   // optional second additive term, same indexing scheme
     long add2_stride;
     int add2_shift;
-    const float *cls;    // optional class conditioning table [n_classes][cls_ld]; added as cls[label[m]*cls_ld + (n % cls_ld)]
-    const int *label;
+    const float *clsrow; // optional per-row conditioning added AFTER `pre` is stored: clsrow[m * cls_ld + (n % cls_ld)]
     int cls_ld;
     int epi;             // EPI_LINEAR / EPI_GATE
     int relu;            // EPI_LINEAR only
     int gateD;           // EPI_GATE: channels per gate half (columns n and n+gateD pair up inside each 2*gateD group)
     float *out;          // EPI_LINEAR: [M][out_stride] N columns; EPI_GATE: [M][out_stride], N/2 columns
     long out_stride;
-    float *pre;          // EPI_GATE optional: pre-activation (acc + bias + add1, without cls) [M][pre_stride]
+    float *pre;          // EPI_GATE optional: pre-activation (acc + bias + add1 + add2, without clsrow) [M][pre_stride]
     long pre_stride;
     int grid_x, grid_y;  // filled by the launcher
-    int debug;           // ablation bits for tools/skinny_chain.py (0 in production)
 };
 
+// up to SKINNY_MAX_PROBLEMS INDEPENDENT problems share one launch (blockIdx.z): one kernel boundary on the dependent chain
 struct SkinnyBatch {
-    SkinnyParams p[2];
+    SkinnyParams p[SKINNY_MAX_PROBLEMS];
 };
 
 hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream);
-// two independent problems in one launch (p1 may be null)
-hipError_t launch_skinny_gemm2(const SkinnyParams *p0, const SkinnyParams *p1, hipStream_t stream);
+hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // VQ / sampling / glue kernels

@@ -81,14 +81,16 @@ int run_skinny(ts_ctx *ctx, const SkinnyParams &p, hipStream_t s) {
     return 0;
 }
 
-int run_skinny2(ts_ctx *ctx, const SkinnyParams &p0, const SkinnyParams &p1, hipStream_t s) {
+int run_skinny_batch(ts_ctx *ctx, const SkinnyParams *const *ps, int n, hipStream_t s) {
+    double fl = 0;
+    for (int i = 0; i < n; ++i) fl += 2.0 * ps[i]->M * (double)ps[i]->N * ps[i]->Ktot;
     ctx->n_launch[FAM_SKINNY] += 1;
-    ctx->n_flops[FAM_SKINNY] += 2.0 * p0.M * (double)p0.N * p0.Ktot + 2.0 * p1.M * (double)p1.N * p1.Ktot;
+    ctx->n_flops[FAM_SKINNY] += fl;
     if (ctx->prof.on) {
         ctx->prof.begin(FAM_SKINNY, s);
-        ctx->prof.flops[FAM_SKINNY] += 2.0 * p0.M * (double)p0.N * p0.Ktot + 2.0 * p1.M * (double)p1.N * p1.Ktot;
+        ctx->prof.flops[FAM_SKINNY] += fl;
     }
-    hipError_t e = launch_skinny_gemm2(&p0, &p1, s);
+    hipError_t e = launch_skinny_batch(ps, n, s);
     if (ctx->prof.on) ctx->prof.end(s);
     if (e != hipSuccess) return fail(std::string("skinny_gemm launch: ") + hipGetErrorString(e));
     return 0;

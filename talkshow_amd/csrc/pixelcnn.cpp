@@ -5,20 +5,24 @@
 // means position (r, j) only needs
 //   * the vertical stack at row r: layer 0 sees code rows r-3..r-1, layer l>=1 sees its own input at rows r-1, r;
 //   * the horizontal stack at columns <= j of row r.
-// So per row we run the vertical stack once for both columns (keeping one previous row per layer), then the
-// horizontal chain for column 0 (body code), sample, then column 1 (hand code), sample: 216x fewer FLOPs, same
-// arithmetic per position (each conv tap is multiplied exactly once, fp32 fmaf accumulation).
+// So per row we run the vertical stack once for both columns, then the horizontal chain for column 0 (body code),
+// sample, then column 1 (hand code), sample: 216x fewer FLOPs, every conv tap multiplied exactly once in fp32.
 //
-// Stage list per row r (every stage = one skinny_gemm launch over all B clips):
-//   v0        h_vert_0 = vert_stack_0(E[codes[r-3..r-1]]) ; OV0 = gate(h_vert_0 + c_0[label])
-//   fuse_v    XV_1[r]  = fusion_v[:, :D] . OV0 + AEV[r]            (AEV = fusion_v[:, D:] . embedding_aud(aud) + biases, precomputed)
-//   v_l       h_vert_l = vert_stack_l(XV_l[r-1], XV_l[r]) ; XV_{l+1}[r] = gate(h_vert_l + c_l)          l = 1..NL-1
-//   v2h_l     V2H_l    = vert_to_horiz_l(h_vert_l)                                                       l = 0..NL-1
-//   for column j = 0, 1:
-//     hg_l    G = gate(V2H_l[j] + horiz_stack_l(XH_l[j-1], XH_l[j]) + c_l)     (layer 0: only column j-1, mask 'A')
-//     hr_l    XH_{l+1}[j] = horiz_resid_l(G) (+ XH_l[j] for l >= 1)
-//     fuse_h  (after layer 0) XH_1[j] = fusion_h[:, :D] . out_h_0 + AEH[r]
-//     head1/2 logits = output_conv(XH_NL[j]) ; sample -> codes[r][j]
+// Row-shifted partial sums (keeps every stage's K at <= 2*dim, i.e. its weight slice small and its MFMA burst short):
+//   h_vert_l(r) = Wcur_l . XV_l[r] + ( Wprev_l . XV_l[r-1] + b )         the bracket is computed one row EARLIER, in the
+//   h_vert_0(r) = W2 . E[r-1] + ( W1 . E[r-2] ) + ( W0 . E[r-3] ) + b     same launch that first sees XV_l[r-1] / E[..]
+//
+// Launch plan of row r (every entry is ONE skinny_gemm launch over all B clips; "|" separates independent problems that
+// share a launch, blockIdx.z):
+//   V0        v0.gate | v0.Q1 | v0.Q0                     gate: OV0 = gate(W2.E[r-1] + Q1[r] + Q0[r] + b + c0)
+//   V1        fuse_v | v2h_0                              XV_1[r] = fusion_v[:, :D].OV0 + AEV[r] ; V2H_0 = v2h(h_vert_0)
+//   V2        v1.gate | v1.P
+//   V_{l+1}   v_l.gate | v_l.P | v2h_{l-1}                l = 2..NL-1
+//   V_{NL+1}  v2h_{NL-1}
+//   column j: hg_0, hr_0, fuse_h, (hg_l, hr_l) l=1..NL-1, head1, head2, sample
+// The vertical stack of a row and the column-0 chain of the same row are independent except for V2H_l, which is ready
+// l+2 launches into the vertical sequence while hg_l sits 2l+1 launches into the column chain — so V_k (k >= 2) rides in
+// the same launch as the (k-2)-th stage of column 0: 70 dependent launches per row instead of 2 + 17 + 66.
 #include <algorithm>
 #include <cstdlib>
 #include <tuple>
@@ -30,21 +34,24 @@ using namespace ts;
 struct ts_pixelcnn {
     ts_ctx *ctx = nullptr;
     int V = 0, D = 0, NL = 0, NC = 0, AD = 0, HID = 512;
-    DevBuf emb;                                   // [V][D]
-    std::vector<std::unique_ptr<DevBuf>> wv, bv;  // vertical: [2*2D][Kv], bias [2*2D] (duplicated per column)
+    DevBuf emb;                                              // [V][D]
+    std::vector<std::vector<std::unique_ptr<DevBuf>>> wvt;   // vertical taps: layer 0 {W0,W1,W2}, l>=1 {Wprev,Wcur}; each [4D][2D]
+    std::vector<std::unique_ptr<DevBuf>> bv;                 // [2*2D] (duplicated per column)
     std::vector<std::unique_ptr<DevBuf>> wv2h, bv2h, wh, bh, cls, wr, br;
-    DevBuf fva, fha;                              // fusion_{v,h}[:, :D]  [D][D]
-    ConvLayer aud_embed, aud_fv, aud_fh;          // embedding_aud ; fusion_{v,h}[:, D:] (+ fusion bias)
-    DevBuf w1, b1, w2, b2;                        // output_conv
+    DevBuf fva, fha;                                         // fusion_{v,h}[:, :D]  [D][D]
+    ConvLayer aud_embed, aud_fv, aud_fh;                     // embedding_aud ; fusion_{v,h}[:, D:] (+ fusion bias)
+    DevBuf w1, b1, w2, b2;                                   // output_conv
     bool use_graph = true;
+    bool pair_vh = true;
     // Work set: every buffer the row loop touches + the hipGraph replays of it.  One per stream, so that independent
     // batches can be in flight on different streams against the single weight copy above.
     struct Work {
         int capB = 0, capH = 0;
-        DevBuf aud_all, AE, AEV, AEH, tok32, label32, XV, OV0, OVlast, HV, V2H, XH, G, OH0, Y, LG, tfcodes;
+        DevBuf aud_all, AE, AEV, AEH, tok32, CR, XV, OV0, OVlast, HV, V2H, P, Q1, Q0, XH, G, OH0, Y, LG, tfcodes;
         // every pointer inside the captured kernels is one of the buffers above or the staging buffers below, so a graph
         // is valid for any caller pointers; key = (B, H, H0, mode)
         DevBuf codes_int, unif_int, dyn;
+        uint64_t dyn_host[2] = {0, 0};   // source of the async H2D copy: must outlive the call
         hipStream_t cap_stream = nullptr;
         std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
         std::map<std::tuple<int, int, int, int>, std::pair<long, double>> graph_stats;   // skinny launches, flops
@@ -81,12 +88,15 @@ int ensure_work(ts_pixelcnn *p, ts_pixelcnn::Work *w, int B, int Htot) {
     TS_TRY(w->AEV.ensure((size_t)cb * ch * D * f));
     TS_TRY(w->AEH.ensure((size_t)cb * ch * D * f));
     TS_TRY(w->tok32.ensure((size_t)cb * ch * 2 * sizeof(int)));
-    TS_TRY(w->label32.ensure((size_t)cb * sizeof(int)));
+    TS_TRY(w->CR.ensure(NL * cb * 2 * D * f));
     TS_TRY(w->XV.ensure(NL * 2 * cb * 2 * D * f));
     TS_TRY(w->OV0.ensure((size_t)cb * 2 * D * f));
     TS_TRY(w->OVlast.ensure((size_t)cb * 2 * D * f));
     TS_TRY(w->HV.ensure(NL * cb * 4 * D * f));
     TS_TRY(w->V2H.ensure(NL * cb * 4 * D * f));
+    TS_TRY(w->P.ensure(NL * 2 * cb * 4 * D * f));
+    TS_TRY(w->Q1.ensure((size_t)4 * cb * 4 * D * f));
+    TS_TRY(w->Q0.ensure((size_t)4 * cb * 4 * D * f));
     TS_TRY(w->XH.ensure((NL + 1) * 2 * cb * D * f));
     TS_TRY(w->G.ensure((size_t)cb * D * f));
     TS_TRY(w->OH0.ensure((size_t)cb * D * f));
@@ -107,8 +117,8 @@ struct RunCfg {
     const float *uniforms;
     uint64_t seed;
     int64_t clip0;
-    int64_t *codes;     // (B,H,2)
-    float *logits;      // (B,H,2,V) or null
+    int64_t *codes;        // (B,H,2)
+    float *logits;         // (B,H,2,V) or null
     const uint64_t *dyn;   // device {seed, clip0} (graph replay) or null
     ts_pixelcnn::Work *w;
 };
@@ -142,56 +152,45 @@ void add_gather(SkinnyParams &q, const float *table, long stride, const int *gid
     q.Ktot += len;
 }
 
-// vertical stack + v->h projections of row r.  Launch plan (NL + 2 launches): v0 | fuse_v + v2h_0 | v_1 |
-// v_2 + v2h_1 | ... | v_{NL-1} + v2h_{NL-2} | v2h_{NL-1}: vert_to_horiz of layer l-1 and the vertical conv of layer l
-// both depend only on layer l-1's output, so they share a launch (two independent problems, blockIdx.z).
-int vertical_row(ts_pixelcnn *p, const RunCfg &c, int r, hipStream_t s) {
-    ts_ctx *ctx = p->ctx;
-    const int B = c.B, D = p->D, NL = p->NL, Htot = c.Htot;
-    const int *tok = c.w->tok32.i();
-    const int *lab = c.w->label32.i();
-    auto XV = [&](int l, int par) { return c.w->XV.f() + ((size_t)(l * 2 + par) * B) * 2 * D; };
-    auto HV = [&](int l) { return c.w->HV.f() + (size_t)l * B * 4 * D; };
-    auto V2H = [&](int l) { return c.w->V2H.f() + (size_t)l * B * 4 * D; };
+struct Slot {   // one launch: up to SKINNY_MAX_PROBLEMS independent problems
+    SkinnyParams p[SKINNY_MAX_PROBLEMS];
+    int n = 0;
+    void add(const SkinnyParams &q) { p[n++] = q; }
+};
 
-    auto make_v = [&](int l) {
-        SkinnyParams q = base_params(B, 4 * D, EPI_GATE);
-        if (l == 0) {
-            for (int t = 0; t < 3; ++t) {
-                const int rr = r - 3 + t;
-                for (int col = 0; col < 2; ++col) {
-                    if (rr >= 0) add_gather(q, p->emb.f(), D, tok + (size_t)rr * 2 + col, (long)Htot * 2, D);
-                    else add_gather(q, p->emb.f(), D, ctx->neg1.i(), 0, D);   // zero padding above the grid
-                }
-            }
-        } else {
-            add_dense(q, r > 0 ? XV(l, (r - 1) & 1) : nullptr, 2 * D, 0, 2 * D);
-            add_dense(q, XV(l, r & 1), 2 * D, 0, 2 * D);
-        }
-        q.W = p->wv[l]->f();
-        q.ldw = q.Ktot;
-        q.bias = p->bv[l]->f();
-        q.cls = p->cls[l]->f();
-        q.label = lab;
+int launch_slot(ts_ctx *ctx, const Slot &a, const Slot *b, hipStream_t s) {
+    const SkinnyParams *ps[SKINNY_MAX_PROBLEMS];
+    int n = 0;
+    for (int i = 0; i < a.n; ++i) ps[n++] = &a.p[i];
+    if (b)
+        for (int i = 0; i < b->n; ++i) ps[n++] = &b->p[i];
+    return run_skinny_batch(ctx, ps, n, s);
+}
+
+// vertical stack + v->h projections of row r as NL+2 launch slots
+void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &out) {
+    const int B = c.B, D = p->D, NL = p->NL, Htot = c.Htot;
+    ts_pixelcnn::Work *w = c.w;
+    const int *tok = w->tok32.i();
+    auto XV = [&](int l, int par) { return w->XV.f() + ((size_t)(l * 2 + par) * B) * 2 * D; };
+    auto HV = [&](int l) { return w->HV.f() + (size_t)l * B * 4 * D; };
+    auto V2H = [&](int l) { return w->V2H.f() + (size_t)l * B * 4 * D; };
+    auto P = [&](int l, int par) { return w->P.f() + ((size_t)(l * 2 + par) * B) * 4 * D; };
+    auto Q = [&](DevBuf &q, int row) { return q.f() + (size_t)(row & 3) * B * 4 * D; };
+    auto CR = [&](int l) { return w->CR.f() + (size_t)l * B * 2 * D; };
+
+    auto gate_common = [&](SkinnyParams &q, int l) {
+        q.ldw = 2 * D;
+        q.clsrow = CR(l);
         q.cls_ld = 2 * D;
         q.gateD = D;
-        q.out = l == 0 ? c.w->OV0.f() : (l + 1 < NL ? XV(l + 1, r & 1) : c.w->OVlast.f());
+        q.out = l == 0 ? w->OV0.f() : (l + 1 < NL ? XV(l + 1, r & 1) : w->OVlast.f());
         q.out_stride = 2 * D;
         q.pre = HV(l);
         q.pre_stride = 4 * D;
-        return q;
     };
-    auto make_fuse_v = [&]() {   // audio fusion in front of layer 1 (gated_pixelcnn_v2.py:137-144)
-        SkinnyParams f = base_params(2 * B, D, EPI_LINEAR);
-        add_dense(f, c.w->OV0.f(), D, 0, D);
-        f.W = p->fva.f();
-        f.ldw = D;
-        f.add1 = c.w->AEV.f() + (size_t)r * D;
-        f.add1_stride = (long)Htot * D;
-        f.add1_shift = 1;
-        f.out = XV(1, r & 1);
-        f.out_stride = D;
-        return f;
+    auto emb_row = [&](SkinnyParams &q, int rr) {   // embeddings of both codes of row rr >= 0
+        for (int col = 0; col < 2; ++col) add_gather(q, p->emb.f(), D, tok + (size_t)rr * 2 + col, (long)Htot * 2, D);
     };
     auto make_v2h = [&](int l) {   // vert_to_horiz on the pre-gate activations, both columns
         SkinnyParams v = base_params(2 * B, 2 * D, EPI_LINEAR);
@@ -204,22 +203,105 @@ int vertical_row(ts_pixelcnn *p, const RunCfg &c, int r, hipStream_t s) {
         return v;
     };
 
-    TS_TRY(run_skinny(ctx, make_v(0), s));
-    if (NL == 1) return run_skinny(ctx, make_v2h(0), s);
-    TS_TRY(run_skinny2(ctx, make_fuse_v(), make_v2h(0), s));
-    TS_TRY(run_skinny(ctx, make_v(1), s));
-    for (int l = 2; l < NL; ++l) TS_TRY(run_skinny2(ctx, make_v(l), make_v2h(l - 1), s));
-    return run_skinny(ctx, make_v2h(NL - 1), s);
+    out.clear();
+    {   // V0: layer 0 (mask 'A', kernel rows 0..2 <-> code rows r-3..r-1): newest row here, older rows via Q1 / Q0.
+        // Rows above the grid contribute nothing: their terms are simply left out (no zero-filled buffers to rely on).
+        Slot s;
+        SkinnyParams g = base_params(B, 4 * D, EPI_GATE);
+        if (r >= 1) emb_row(g, r - 1);
+        g.W = p->wvt[0][2]->f();
+        g.bias = p->bv[0]->f();
+        if (r >= 2) {
+            g.add1 = Q(w->Q1, r);      // W1 . E[r-2], computed by the launch of row r-1
+            g.add1_stride = 4 * D;
+        }
+        if (r >= 3) {
+            g.add2 = Q(w->Q0, r);      // W0 . E[r-3], computed by the launch of row r-2
+            g.add2_stride = 4 * D;
+        }
+        gate_common(g, 0);
+        s.add(g);
+        for (int t = 1; t >= 0 && r >= 1; --t) {   // row r-1's codes as seen from row r+1 (kernel row 1) and r+2 (kernel row 0)
+            const int target = r + (2 - t);
+            if (target >= Htot) continue;
+            SkinnyParams q = base_params(B, 4 * D, EPI_LINEAR);
+            emb_row(q, r - 1);
+            q.W = p->wvt[0][t]->f();
+            q.ldw = 2 * D;
+            q.out = Q(t == 1 ? w->Q1 : w->Q0, target);
+            q.out_stride = 4 * D;
+            s.add(q);
+        }
+        out.push_back(s);
+    }
+    if (NL == 1) {
+        Slot s;
+        s.add(make_v2h(0));
+        out.push_back(s);
+        return;
+    }
+    {   // V1: audio fusion in front of layer 1 (gated_pixelcnn_v2.py:137-144) | v2h_0
+        Slot s;
+        SkinnyParams f = base_params(2 * B, D, EPI_LINEAR);
+        add_dense(f, w->OV0.f(), D, 0, D);
+        f.W = p->fva.f();
+        f.ldw = D;
+        f.add1 = w->AEV.f() + (size_t)r * D;
+        f.add1_stride = (long)Htot * D;
+        f.add1_shift = 1;
+        f.out = XV(1, r & 1);
+        f.out_stride = D;
+        s.add(f);
+        s.add(make_v2h(0));
+        out.push_back(s);
+    }
+    for (int l = 1; l < NL; ++l) {   // V_{l+1}: v_l.gate | v_l.P | v2h_{l-1}
+        Slot s;
+        SkinnyParams g = base_params(B, 4 * D, EPI_GATE);
+        add_dense(g, XV(l, r & 1), 2 * D, 0, 2 * D);
+        g.W = p->wvt[l][1]->f();
+        if (r > 0) {
+            g.add1 = P(l, r & 1);          // Wprev . XV_l[r-1] + bias, computed while row r-1 ran
+            g.add1_stride = 4 * D;
+        } else {
+            g.bias = p->bv[l]->f();        // nothing above the first row
+        }
+        gate_common(g, l);
+        s.add(g);
+        if (r + 1 < Htot) {
+            SkinnyParams q = base_params(B, 4 * D, EPI_LINEAR);
+            add_dense(q, XV(l, r & 1), 2 * D, 0, 2 * D);
+            q.W = p->wvt[l][0]->f();
+            q.ldw = 2 * D;
+            q.bias = p->bv[l]->f();
+            q.out = P(l, (r + 1) & 1);
+            q.out_stride = 4 * D;
+            s.add(q);
+        }
+        if (l >= 2) s.add(make_v2h(l - 1));
+        out.push_back(s);
+    }
+    {
+        Slot s;
+        s.add(make_v2h(NL - 1));
+        out.push_back(s);
+    }
 }
 
-// horizontal chain + head + sampler for position (r, j)
-int horizontal_pos(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s) {
-    ts_ctx *ctx = p->ctx;
+// horizontal chain + head of position (r, j) as single-problem slots (the sampler launch follows separately)
+void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector<Slot> &out) {
     const int B = c.B, D = p->D, NL = p->NL, Htot = c.Htot;
-    const int *tok = c.w->tok32.i();
-    auto V2H = [&](int l) { return c.w->V2H.f() + (size_t)l * B * 4 * D; };
-    auto XH = [&](int l, int col) { return c.w->XH.f() + ((size_t)(l * 2 + col) * B) * D; };
-
+    ts_pixelcnn::Work *w = c.w;
+    const int *tok = w->tok32.i();
+    auto V2H = [&](int l) { return w->V2H.f() + (size_t)l * B * 4 * D; };
+    auto XH = [&](int l, int col) { return w->XH.f() + ((size_t)(l * 2 + col) * B) * D; };
+    auto CR = [&](int l) { return w->CR.f() + (size_t)l * B * 2 * D; };
+    auto push = [&](const SkinnyParams &q) {
+        Slot s;
+        s.add(q);
+        out.push_back(s);
+    };
+    out.clear();
     for (int l = 0; l < NL; ++l) {
         SkinnyParams q = base_params(B, 2 * D, EPI_GATE);
         q.ldw = 2 * D;
@@ -237,66 +319,68 @@ int horizontal_pos(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s)
         q.bias = p->bh[l]->f();
         q.add1 = V2H(l) + (size_t)j * 2 * D;
         q.add1_stride = 4 * D;
-        q.cls = p->cls[l]->f();
-        q.label = c.w->label32.i();
+        q.clsrow = CR(l);
         q.cls_ld = 2 * D;
         q.gateD = D;
-        q.out = c.w->G.f();
+        q.out = w->G.f();
         q.out_stride = D;
-        TS_TRY(run_skinny(ctx, q, s));
+        push(q);
 
         SkinnyParams h = base_params(B, D, EPI_LINEAR);
-        add_dense(h, c.w->G.f(), D, 0, D);
+        add_dense(h, w->G.f(), D, 0, D);
         h.W = p->wr[l]->f();
         h.ldw = D;
         h.bias = p->br[l]->f();
         if (l == 0) {
-            h.out = c.w->OH0.f();
+            h.out = w->OH0.f();
         } else {
             h.add1 = XH(l, j);
             h.add1_stride = D;
             h.out = XH(l + 1, j);
         }
         h.out_stride = D;
-        TS_TRY(run_skinny(ctx, h, s));
+        push(h);
 
         if (l == 0 && NL > 1) {
             SkinnyParams f = base_params(B, D, EPI_LINEAR);
-            add_dense(f, c.w->OH0.f(), D, 0, D);
+            add_dense(f, w->OH0.f(), D, 0, D);
             f.W = p->fha.f();
             f.ldw = D;
-            f.add1 = c.w->AEH.f() + (size_t)r * D;
+            f.add1 = w->AEH.f() + (size_t)r * D;
             f.add1_stride = (long)Htot * D;
             f.out = XH(1, j);
             f.out_stride = D;
-            TS_TRY(run_skinny(ctx, f, s));
+            push(f);
         }
     }
-    const float *xfin = NL > 1 ? XH(NL, j) : c.w->OH0.f();
+    const float *xfin = NL > 1 ? XH(NL, j) : w->OH0.f();
     SkinnyParams h1 = base_params(B, p->HID, EPI_LINEAR);
     add_dense(h1, xfin, D, 0, D);
     h1.W = p->w1.f();
     h1.ldw = D;
     h1.bias = p->b1.f();
     h1.relu = 1;
-    h1.out = c.w->Y.f();
+    h1.out = w->Y.f();
     h1.out_stride = p->HID;
-    TS_TRY(run_skinny(ctx, h1, s));
+    push(h1);
 
     SkinnyParams h2 = base_params(B, p->V, EPI_LINEAR);
-    add_dense(h2, c.w->Y.f(), p->HID, 0, p->HID);
+    add_dense(h2, w->Y.f(), p->HID, 0, p->HID);
     h2.W = p->w2.f();
     h2.ldw = p->HID;
     h2.bias = p->b2.f();
-    h2.out = c.w->LG.f();
+    h2.out = w->LG.f();
     h2.out_stride = p->V;
-    TS_TRY(run_skinny(ctx, h2, s));
+    push(h2);
+}
 
+int launch_sampler(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s) {
+    ts_pixelcnn::Work *w = c.w;
     SampleParams sp;
     std::memset(&sp, 0, sizeof(sp));
     const int ro = r - c.H0;   // row in the caller's (B,H,2) arrays
-    sp.logits = c.w->LG.f();
-    sp.B = B;
+    sp.logits = w->LG.f();
+    sp.B = c.B;
     sp.V = p->V;
     sp.mode = c.mode;
     sp.uniforms = c.uniforms ? c.uniforms + (size_t)ro * 2 + j : nullptr;
@@ -305,19 +389,46 @@ int horizontal_pos(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s)
     sp.clip_index0 = c.clip0;
     sp.dyn = c.dyn;
     sp.position = (uint32_t)(ro * 2 + j);
-    sp.tok32 = c.w->tok32.i() + (size_t)r * 2 + j;
-    sp.tok_stride = (long)Htot * 2;
+    sp.tok32 = w->tok32.i() + (size_t)r * 2 + j;
+    sp.tok_stride = (long)c.Htot * 2;
     sp.codes = c.codes + (size_t)ro * 2 + j;
     sp.code_stride = (long)c.H * 2;
     if (c.logits) {
         sp.logits_copy = c.logits + ((size_t)ro * 2 + j) * p->V;
         sp.copy_stride = (long)c.H * 2 * p->V;
     }
-    {
-        MiscScope ms(ctx, s);
-        TS_HIP(launch_sample(sp, s));
-    }
+    MiscScope ms(p->ctx, s);
+    TS_HIP(launch_sample(sp, s));
     return 0;
+}
+
+int run_row(ts_pixelcnn *p, const RunCfg &c, int r, bool need_h, hipStream_t s) {
+    ts_ctx *ctx = p->ctx;
+    std::vector<Slot> V, H;
+    build_vertical(p, c, r, V);
+    if (!need_h) {
+        for (auto &sl : V) TS_TRY(launch_slot(ctx, sl, nullptr, s));
+        return 0;
+    }
+    build_horizontal(p, c, r, 0, H);
+    size_t vi = 0;
+    if (p->pair_vh) {
+        // V0, V1 alone (hg_0 needs V2H_0); then V_k rides with the (k-2)-th stage of column 0
+        for (; vi < 2 && vi < V.size(); ++vi) TS_TRY(launch_slot(ctx, V[vi], nullptr, s));
+        for (size_t k = 0; k < H.size(); ++k) {
+            const Slot *ride = nullptr;
+            if (vi < V.size() && V[vi].n + H[k].n <= SKINNY_MAX_PROBLEMS) ride = &V[vi++];
+            TS_TRY(launch_slot(ctx, H[k], ride, s));
+        }
+        for (; vi < V.size(); ++vi) TS_TRY(launch_slot(ctx, V[vi], nullptr, s));   // only if the stack outlasts the chain
+    } else {
+        for (auto &sl : V) TS_TRY(launch_slot(ctx, sl, nullptr, s));
+        for (auto &sl : H) TS_TRY(launch_slot(ctx, sl, nullptr, s));
+    }
+    TS_TRY(launch_sampler(p, c, r, 0, s));
+    build_horizontal(p, c, r, 1, H);
+    for (auto &sl : H) TS_TRY(launch_slot(ctx, sl, nullptr, s));
+    return launch_sampler(p, c, r, 1, s);
 }
 
 }  // namespace
@@ -343,6 +454,7 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
     if (!emb) return 1;
     TS_TRY(p->emb.upload(emb, (size_t)V * D * sizeof(float)));
 
+    p->wvt.resize(NL);
     for (int l = 0; l < NL; ++l) {
         const std::string q = "layers." + std::to_string(l);
         const int kh = l == 0 ? 4 : 2;       // kernel // 2 + 1 rows, kernel = 7 / 3 (gated_pixelcnn_v2.py:34,112-113)
@@ -357,19 +469,20 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
         const float *wr = sd.get(q + ".horiz_resid.weight", {D, D, 1, 1});
         const float *br = sd.get(q + ".horiz_resid.bias", {D});
         if (!wv || !bv || !wvh || !bvh || !wh || !bh || !cl || !wr || !br) return 1;
-        // vertical: output n = (col j, channel co); k = ((row tap t)*2 + input col c)*D + ci; kernel column c - j + 1
-        const int Kv = rows * 2 * D;
-        std::vector<float> pv((size_t)2 * D2 * Kv), pb((size_t)2 * D2);
+        // one matrix per kernel row t: output n = (col j, channel co); k = (input col c)*D + ci; kernel column c - j + 1
+        std::vector<float> pb((size_t)2 * D2);
         for (int j = 0; j < 2; ++j)
-            for (int co = 0; co < D2; ++co) {
-                pb[(size_t)j * D2 + co] = bv[co];
-                for (int t = 0; t < rows; ++t)
+            for (int co = 0; co < D2; ++co) pb[(size_t)j * D2 + co] = bv[co];
+        for (int t = 0; t < rows; ++t) {
+            std::vector<float> pv((size_t)2 * D2 * 2 * D);
+            for (int j = 0; j < 2; ++j)
+                for (int co = 0; co < D2; ++co)
                     for (int cc = 0; cc < 2; ++cc)
                         for (int ci = 0; ci < D; ++ci)
-                            pv[((size_t)j * D2 + co) * Kv + ((size_t)t * 2 + cc) * D + ci] =
+                            pv[((size_t)j * D2 + co) * 2 * D + (size_t)cc * D + ci] =
                                 wv[(((size_t)co * D + ci) * kh + t) * 3 + (cc - j + 1)];
-            }
-        TS_TRY(upload_vec(p->wv, pv));
+            TS_TRY(upload_vec(p->wvt[l], pv));
+        }
         TS_TRY(upload_vec(p->bv, pb));
         TS_TRY(upload_vec(p->wv2h, std::vector<float>(wvh, wvh + (size_t)D2 * D2)));
         TS_TRY(upload_vec(p->bv2h, std::vector<float>(bvh, bvh + D2)));
@@ -411,6 +524,7 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
     TS_TRY(p->w2.upload(w2, (size_t)V * p->HID * sizeof(float)));
     TS_TRY(p->b2.upload(b2, (size_t)V * sizeof(float)));
     if (const char *e = std::getenv("TS_NO_GRAPH")) p->use_graph = !(e[0] && e[0] != '0');
+    if (const char *e = std::getenv("TS_NO_PAIR")) p->pair_vh = !(e[0] && e[0] != '0');
     *out = p.release();
     return 0;
 }
@@ -437,11 +551,11 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
     if (H0 > 0 && (!pre_codes || !pre_aud)) return fail("ts_pixelcnn_generate: prefix pointers required");
     hipStream_t s = (hipStream_t)stream;
     ts_ctx *ctx = p->ctx;
-    const int Htot = H0 + H, D = p->D, AD = p->AD;
+    const int Htot = H0 + H, D = p->D, AD = p->AD, NL = p->NL;
     ts_pixelcnn::Work *w = &p->work(s);
     TS_TRY(ensure_work(p, w, B, Htot));
 
-    // The row loop is replayed from a hipGraph (host launch cost would otherwise dominate: ~100 dependent tiny
+    // The row loop is replayed from a hipGraph (host launch cost would otherwise dominate: 70 dependent tiny
     // launches per row); eager launches remain for the instrumented / logits-returning / teacher-forced paths.
     const bool graph = p->use_graph && !ctx->prof.on && !logits && mode != TS_TEACHER_FORCED;
     RunCfg c{B, H, H0, Htot, mode, uniforms, seed, clip0, codes, logits, nullptr, w};
@@ -472,7 +586,9 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
     }
     {
         MiscScope ms(ctx, s);
-        TS_HIP(launch_i64_to_i32(label, w->label32.i(), B, s));
+        // class conditioning rows: CR[l][b] = class_cond_embedding_l[label[b]]  (h of gated_pixelcnn_v2.py:65)
+        for (int l = 0; l < NL; ++l)
+            TS_HIP(launch_gather_rows(p->cls[l]->f(), 2 * D, label, 1, B, 2 * D, w->CR.f() + (size_t)l * B * 2 * D, 2 * D, s));
         // known codes: the continuity prefix, and every position when teacher forced
         if (H0 > 0 || mode == TS_TEACHER_FORCED) {
             int64_t *tf = static_cast<int64_t *>(w->tfcodes.p);
@@ -489,10 +605,8 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
 
     auto row_loop = [&](hipStream_t st) -> int {
         for (int r = 0; r < Htot; ++r) {
-            TS_TRY(vertical_row(p, c, r, st));
-            if (r < H0) continue;                                         // prefix rows only feed the row cache
-            if (mode == TS_TEACHER_FORCED && !logits) continue;           // nothing to produce
-            for (int j = 0; j < 2; ++j) TS_TRY(horizontal_pos(p, c, r, j, st));
+            const bool need_h = r >= H0 && !(mode == TS_TEACHER_FORCED && !logits);   // prefix rows only feed the row cache
+            TS_TRY(run_row(p, c, r, need_h, st));
         }
         return 0;
     };
@@ -500,8 +614,10 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
 
     if (mode == TS_SAMPLE_UNIFORMS)
         TS_HIP(hipMemcpyAsync(w->unif_int.p, uniforms, (size_t)B * H * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    const uint64_t dynh[2] = {seed, (uint64_t)clip0};
-    TS_HIP(hipMemcpyAsync(w->dyn.p, dynh, sizeof(dynh), hipMemcpyHostToDevice, s));   // pageable: staged before return
+    // the copy is made synchronous w.r.t. the host buffer: one generate per Work at a time (single host thread)
+    w->dyn_host[0] = seed;
+    w->dyn_host[1] = (uint64_t)clip0;
+    TS_HIP(hipMemcpyAsync(w->dyn.p, w->dyn_host, sizeof(w->dyn_host), hipMemcpyHostToDevice, s));
     const auto key = std::make_tuple(B, H, H0, mode);
     auto it = w->graphs.find(key);
     if (it == w->graphs.end()) {

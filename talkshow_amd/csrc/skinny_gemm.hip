@@ -23,8 +23,8 @@ template <int W>
 __global__ __launch_bounds__(W * 64) void skinny_gemm_kernel(const SkinnyBatch batch) {
     __shared__ float red[W][16][64];
 
-    // up to two INDEPENDENT problems share one launch (e.g. vert_to_horiz of layer l and the vertical conv of layer
-    // l+1 both only need layer l's output): one kernel boundary instead of two on the dependent chain.
+    // several INDEPENDENT problems share one launch (e.g. a horizontal-chain stage of this row, the vertical conv of
+    // layer l and vert_to_horiz of layer l-1): one kernel boundary instead of three on the dependent chain.
     const SkinnyParams &p = batch.p[blockIdx.z];
     if ((int)blockIdx.x >= p.grid_x || (int)blockIdx.y >= p.grid_y) return;
 
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(W * 64) void skinny_gemm_kernel(const SkinnyBatch b
         if (p.add1) a += p.add1[(long)(rowc >> p.add1_shift) * p.add1_stride + nc];
         if (p.add2) a += p.add2[(long)(rowc >> p.add2_shift) * p.add2_stride + nc];
         e_add[rr] = a;
-        e_cls[rr] = (p.epi == EPI_GATE && p.cls) ? p.cls[(long)p.label[rowc] * p.cls_ld + (nc % p.cls_ld)] : 0.f;
+        e_cls[rr] = (p.epi == EPI_GATE && p.clsrow) ? p.clsrow[(long)rowc * p.cls_ld + (nc % p.cls_ld)] : 0.f;
     }
 
     const int Q = p.Ktot >> 3;
@@ -152,144 +152,6 @@ __global__ __launch_bounds__(W * 64) void skinny_gemm_kernel(const SkinnyBatch b
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// v2: every wave issues ALL of its operand loads before the first MFMA (one memory round trip per launch instead of
-// one per 4 q-steps), and each lane reads ONE contiguous run of k (QW*16 bytes, a whole 64/128-byte line for QW = 4/8)
-// of its weight row / activation row: the lane half h takes the first / second half of the wave's k range — a
-// permutation of the K order applied identically to A and B.  QW = q-steps (8 k each) per wave.
-// debug bits (ablation, tools/skinny_chain.py): 1 no weight loads, 2 no activation loads, 4 no MFMA, 8 no tanh/exp.
-// ---------------------------------------------------------------------------------------------------------------
-template <int W, int QW>
-__global__ __launch_bounds__(W * 64) void skinny_gemm_kernel_v2(const SkinnyBatch batch) {
-    __shared__ float red[W][16][64];
-    const SkinnyParams &p = batch.p[blockIdx.z];
-    if ((int)blockIdx.x >= p.grid_x || (int)blockIdx.y >= p.grid_y) return;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int tile = blockIdx.x, mt = blockIdx.y;
-    const int dbg = p.debug;
-
-    int n;
-    if (p.epi == EPI_GATE) {
-        const int tiles_per_group = p.gateD >> 4;
-        const int group = tile / tiles_per_group, ch0 = (tile - group * tiles_per_group) << 4;
-        n = group * 2 * p.gateD + (li >> 4) * p.gateD + ch0 + (li & 15);
-    } else {
-        n = tile * 32 + li;
-    }
-    const bool n_ok = n < p.N;
-    const float *wrow = p.W + (long)(n_ok ? n : 0) * p.ldw;
-
-    const int m = mt * 32 + li;
-    const bool m_ok = m < p.M;
-
-    // activation row pointer of this lane in every segment (gather indices are the only dependent loads)
-    const float *arow[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        arow[s] = nullptr;
-        if (s < p.nseg && m_ok) {
-            const SkinnySeg &sg = p.seg[s];
-            if (sg.gidx) {
-                const int gi = sg.gidx[(long)m * sg.gidx_stride];
-                if (gi >= 0) arow[s] = sg.base + (long)gi * sg.row_stride;
-            } else if (sg.base) {
-                arow[s] = sg.base + (long)(m >> sg.row_shift) * sg.row_stride;
-            }
-        }
-    }
-
-    constexpr int RPW = 16 / W;
-    float e_add[RPW], e_cls[RPW];
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-        const int r = wave * RPW + rr;
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int rowc = row < p.M ? row : 0;
-        const int nc = n_ok ? n : 0;
-        float a = 0.f;
-        if (p.bias) a += p.bias[nc];
-        if (p.add1) a += p.add1[(long)(rowc >> p.add1_shift) * p.add1_stride + nc];
-        if (p.add2) a += p.add2[(long)(rowc >> p.add2_shift) * p.add2_stride + nc];
-        e_add[rr] = a;
-        e_cls[rr] = (p.epi == EPI_GATE && p.cls) ? p.cls[(long)p.label[rowc] * p.cls_ld + (nc % p.cls_ld)] : 0.f;
-    }
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    const int Q = p.Ktot >> 3;
-    const int q0 = wave * QW;
-    const int nq = Q - q0 < QW ? Q - q0 : QW;   // q-steps of this wave (<= 0: idle)
-    if (nq > 0) {
-        const int kbase = q0 * 8 + lh * nq * 4;
-        f32x4 a[QW], b[QW];
-#pragma unroll
-        for (int u = 0; u < QW; ++u) {
-            a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            b[u] = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (u < nq) {
-                const int k = kbase + u * 4;
-                if (!(dbg & 1)) b[u] = *reinterpret_cast<const f32x4 *>(wrow + k);
-                const float *ap = nullptr;
-                int ks = 0;
-#pragma unroll
-                for (int s = 0; s < 6; ++s) {
-                    if (s < p.nseg) {
-                        const int len = p.seg[s].len;
-                        if (k >= ks && k < ks + len && arow[s]) ap = arow[s] + (k - ks);
-                        ks += len;
-                    }
-                }
-                if (ap && !(dbg & 2)) a[u] = *reinterpret_cast<const f32x4 *>(ap);
-            }
-        }
-        if (!(dbg & 4)) {
-#pragma unroll
-            for (int u = 0; u < QW; ++u)
-                if (u < nq) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e], acc, 0, 0, 0);
-                }
-        } else {
-#pragma unroll
-            for (int u = 0; u < QW; ++u) acc[u & 15] += a[u][0] + b[u][0];
-        }
-    }
-
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    __syncthreads();
-
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-        const int r = wave * RPW + rr;
-        float v = red[0][r][lane];
-#pragma unroll
-        for (int w = 1; w < W; ++w) v += red[w][r][lane];
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const bool ok = n_ok && row < p.M;
-        v += e_add[rr];
-        if (p.epi == EPI_GATE) {
-            if (p.pre && ok) p.pre[(long)row * p.pre_stride + n] = v;
-            v += e_cls[rr];
-            const float partner = __shfl_xor(v, 16);
-            if ((li & 16) == 0 && ok) {
-                const float gate = (dbg & 8) ? v + partner : tanhf(v) * (1.0f / (1.0f + expf(-partner)));
-                const int tiles_per_group = p.gateD >> 4;
-                const int group = tile / tiles_per_group, ch0 = (tile - group * tiles_per_group) << 4;
-                p.out[(long)row * p.out_stride + group * p.gateD + ch0 + (li & 15)] = gate;
-            }
-        } else {
-            if (p.relu) v = v > 0.f ? v : 0.f;
-            if (ok) p.out[(long)row * p.out_stride + n] = v;
-        }
-    }
-}
-
 static int skinny_grid(SkinnyParams &p) {
     if (p.Ktot % 8 != 0 || p.M <= 0) return -1;
     if (p.epi == EPI_GATE) {
@@ -302,33 +164,20 @@ static int skinny_grid(SkinnyParams &p) {
     return 0;
 }
 
-hipError_t launch_skinny_gemm2(const SkinnyParams *p0, const SkinnyParams *p1, hipStream_t stream) {
+hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t stream) {
+    if (n < 1 || n > SKINNY_MAX_PROBLEMS) return hipErrorInvalidValue;
     SkinnyBatch b;
-    b.p[0] = *p0;
-    if (skinny_grid(b.p[0])) return hipErrorInvalidValue;
-    int gx = b.p[0].grid_x, gy = b.p[0].grid_y, Q = b.p[0].Ktot / 8, nz = 1;
-    if (p1) {
-        b.p[1] = *p1;
-        if (skinny_grid(b.p[1])) return hipErrorInvalidValue;
-        gx = gx > b.p[1].grid_x ? gx : b.p[1].grid_x;
-        gy = gy > b.p[1].grid_y ? gy : b.p[1].grid_y;
-        Q = Q > b.p[1].Ktot / 8 ? Q : b.p[1].Ktot / 8;
-        nz = 2;
+    int gx = 0, gy = 0, Q = 0;
+    for (int i = 0; i < n; ++i) {
+        b.p[i] = *ps[i];
+        if (b.p[i].nseg > SKINNY_MAX_SEG || skinny_grid(b.p[i])) return hipErrorInvalidValue;
+        gx = gx > b.p[i].grid_x ? gx : b.p[i].grid_x;
+        gy = gy > b.p[i].grid_y ? gy : b.p[i].grid_y;
+        Q = Q > b.p[i].Ktot / 8 ? Q : b.p[i].Ktot / 8;
     }
-    dim3 grid(gx, gy, nz);
-    static const int version = [] { const char *e = getenv("TS_SKINNY_V"); return e ? atoi(e) : 1; }();
-    if (version == 2) {
-        // QW q-steps (of 8 k) per wave, W waves: all loads of a wave in flight at once
-        if (Q <= 16) hipLaunchKernelGGL((skinny_gemm_kernel_v2<4, 4>), grid, dim3(256), 0, stream, b);
-        else if (Q <= 32) hipLaunchKernelGGL((skinny_gemm_kernel_v2<8, 4>), grid, dim3(512), 0, stream, b);
-        else if (Q <= 64) hipLaunchKernelGGL((skinny_gemm_kernel_v2<16, 4>), grid, dim3(1024), 0, stream, b);
-        else if (Q <= 128) hipLaunchKernelGGL((skinny_gemm_kernel_v2<16, 8>), grid, dim3(1024), 0, stream, b);
-        else if (Q <= 192) hipLaunchKernelGGL((skinny_gemm_kernel_v2<16, 12>), grid, dim3(1024), 0, stream, b);
-        else return hipErrorInvalidValue;
-        return hipGetLastError();
-    }
+    dim3 grid(gx, gy, n);
     // K is split over the waves of the workgroup; more waves = more loads in flight (lower latency for ONE chain) but a
-    // fatter workgroup (fewer independent chains fit on the chip at once).  TS_SKINNY_MAXW caps it (tuning).
+    // fatter workgroup.  TS_SKINNY_MAXW caps it (tuning).
     static const int maxw = [] { const char *e = getenv("TS_SKINNY_MAXW"); return e ? atoi(e) : 16; }();
     int W = Q >= 64 ? 16 : (Q >= 32 ? 8 : 4);
     if (W > maxw) W = maxw;
@@ -338,6 +187,9 @@ hipError_t launch_skinny_gemm2(const SkinnyParams *p0, const SkinnyParams *p1, h
     return hipGetLastError();
 }
 
-hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream) { return launch_skinny_gemm2(&p, nullptr, stream); }
+hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream) {
+    const SkinnyParams *ps[1] = {&p};
+    return launch_skinny_batch(ps, 1, stream);
+}
 
 }  // namespace ts
