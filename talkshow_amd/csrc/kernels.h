@@ -71,7 +71,7 @@ struct SkinnySeg {
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1 };
 constexpr int SKINNY_MAX_SEG = 3;
-constexpr int SKINNY_MAX_PROBLEMS = 4;
+constexpr int SKINNY_MAX_PROBLEMS = 6;
 
 struct SkinnyParams {
     int M, N;            // N = number of weight rows (EPI_GATE: 2*gateD per group)
@@ -86,6 +86,8 @@ struct SkinnyParams {
     const float *add2;   // optional second additive term, same indexing scheme
     long add2_stride;
     int add2_shift;
+    const float *add3;   // optional third additive term: add3[m * add3_stride + n]
+    long add3_stride;
     const float *clsrow; // optional per-row conditioning added AFTER `pre` is stored: clsrow[m * cls_ld + (n % cls_ld)]
     int cls_ld;
     int epi;             // EPI_LINEAR / EPI_GATE

@@ -19,10 +19,19 @@
 //   V2        v1.gate | v1.P
 //   V_{l+1}   v_l.gate | v_l.P | v2h_{l-1}                l = 2..NL-1
 //   V_{NL+1}  v2h_{NL-1}
-//   column j: hg_0, hr_0, fuse_h, (hg_l, hr_l) l=1..NL-1, head1, head2, sample
-// The vertical stack of a row and the column-0 chain of the same row are independent except for V2H_l, which is ready
-// l+2 launches into the vertical sequence while hg_l sits 2l+1 launches into the column chain — so V_k (k >= 2) rides in
-// the same launch as the (k-2)-th stage of column 0: 70 dependent launches per row instead of 2 + 17 + 66.
+//   column j: hg_0, S_1 .. S_{NL-1}, head1', head2, sample
+//
+// Horizontal chain, one launch per layer.  In the reference a layer is gate(horiz_stack(x_h) + ...) followed by
+// horiz_resid (+ x_h), i.e. two dependent linear maps per layer; consecutive linear maps are composed on the host
+// (products in fp64, rounded once to fp32 — the same kind of fold as BatchNorm into a conv):
+//   S_l   A: XH_l[j]  = Rw_l . G_{l-1} + rb_l + XH_{l-1}[j]                               (Rw_l = horiz_resid_{l-1};
+//         B: G_l      = gate( (Wh1_l.Rw_l) . G_{l-1} + Wh1_l . XH_{l-1}[j] + bm_l          l = 1 also folds fusion_h)
+//                             + V2H_l[j] + c_l  [+ Wh0_l . XH_l[0] for j = 1, precomputed while column 0 ran] )
+//   head1'   relu( (W1.Wr_{NL-1}) . G_{NL-1} + W1 . XH_{NL-1}[j] + b )
+// A and B only need (G_{l-1}, XH_{l-1}) so they share a launch: NL + 2 dependent launches per column instead of 2*NL + 3.
+// The vertical stack of a row and the column-0 chain of the same row are independent except for V2H_l (ready after
+// V_{l+2}); V_k rides in the launch of the column-0 stage that runs one step behind it: 2 + (NL + 4) + (NL + 2) + 2
+// = 40 dependent launches per row for NL = 15 instead of 2 + 17 + 66.
 #include <algorithm>
 #include <cstdlib>
 #include <tuple>
@@ -41,13 +50,18 @@ struct ts_pixelcnn {
     DevBuf fva, fha;                                         // fusion_{v,h}[:, :D]  [D][D]
     ConvLayer aud_embed, aud_fv, aud_fh;                     // embedding_aud ; fusion_{v,h}[:, D:] (+ fusion bias)
     DevBuf w1, b1, w2, b2;                                   // output_conv
+    // composed horizontal maps (see the header): per layer l >= 1
+    std::vector<std::unique_ptr<DevBuf>> rw, rb;             // A: Rw_l [D][D], rb_l [D]        (index l, entry 0 unused)
+    std::vector<std::unique_ptr<DevBuf>> wB, bm;             // B: [2D][D or 2D], bm_l [2D]
+    DevBuf w1m, b1m;                                         // head1': [HID][D or 2D], [HID]
+    ConvLayer aud_h1;                                        // Wh1_1 applied to AEH for every row (l = 1 has AEH in place of XH_0)
     bool use_graph = true;
     bool pair_vh = true;
     // Work set: every buffer the row loop touches + the hipGraph replays of it.  One per stream, so that independent
     // batches can be in flight on different streams against the single weight copy above.
     struct Work {
         int capB = 0, capH = 0;
-        DevBuf aud_all, AE, AEV, AEH, tok32, CR, XV, OV0, OVlast, HV, V2H, P, Q1, Q0, XH, G, OH0, Y, LG, tfcodes;
+        DevBuf aud_all, AE, AEV, AEH, AEH1, tok32, CR, XV, OV0, OVlast, HV, V2H, P, Q1, Q0, XH, G, T0, Y, LG, tfcodes;
         // every pointer inside the captured kernels is one of the buffers above or the staging buffers below, so a graph
         // is valid for any caller pointers; key = (B, H, H0, mode)
         DevBuf codes_int, unif_int, dyn;
@@ -98,8 +112,9 @@ int ensure_work(ts_pixelcnn *p, ts_pixelcnn::Work *w, int B, int Htot) {
     TS_TRY(w->Q1.ensure((size_t)4 * cb * 4 * D * f));
     TS_TRY(w->Q0.ensure((size_t)4 * cb * 4 * D * f));
     TS_TRY(w->XH.ensure((NL + 1) * 2 * cb * D * f));
-    TS_TRY(w->G.ensure((size_t)cb * D * f));
-    TS_TRY(w->OH0.ensure((size_t)cb * D * f));
+    TS_TRY(w->G.ensure((size_t)2 * cb * D * f));
+    TS_TRY(w->T0.ensure(NL * cb * 2 * D * f));
+    TS_TRY(w->AEH1.ensure((size_t)cb * ch * 2 * D * f));
     TS_TRY(w->Y.ensure((size_t)cb * p->HID * f));
     TS_TRY(w->LG.ensure((size_t)cb * p->V * f));
     TS_TRY(w->tfcodes.ensure((size_t)cb * ch * 2 * sizeof(int64_t)));
@@ -288,90 +303,113 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
     }
 }
 
-// horizontal chain + head of position (r, j) as single-problem slots (the sampler launch follows separately)
+// horizontal chain + head of position (r, j): NL + 2 launch slots (the sampler launch follows separately)
 void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector<Slot> &out) {
     const int B = c.B, D = p->D, NL = p->NL, Htot = c.Htot;
     ts_pixelcnn::Work *w = c.w;
     const int *tok = w->tok32.i();
-    auto V2H = [&](int l) { return w->V2H.f() + (size_t)l * B * 4 * D; };
+    auto V2H = [&](int l) { return w->V2H.f() + (size_t)l * B * 4 * D + (size_t)j * 2 * D; };
     auto XH = [&](int l, int col) { return w->XH.f() + ((size_t)(l * 2 + col) * B) * D; };
     auto CR = [&](int l) { return w->CR.f() + (size_t)l * B * 2 * D; };
-    auto push = [&](const SkinnyParams &q) {
-        Slot s;
-        s.add(q);
-        out.push_back(s);
+    auto G = [&](int l) { return w->G.f() + (size_t)(l & 1) * B * D; };
+    auto T0 = [&](int l) { return w->T0.f() + (size_t)l * B * 2 * D; };
+    auto make_t0 = [&](int l) {   // column 0 only: Wh0_l . XH_l[0], consumed by column 1's S_l
+        SkinnyParams t = base_params(B, 2 * D, EPI_LINEAR);
+        add_dense(t, XH(l, 0), D, 0, D);
+        t.W = p->wh[l]->f();      // tap 0 block
+        t.ldw = 2 * D;
+        t.out = T0(l);
+        t.out_stride = 2 * D;
+        return t;
     };
     out.clear();
-    for (int l = 0; l < NL; ++l) {
+    {   // hg_0 — mask 'A': only the column to the left, i.e. the embedding of the code just sampled
+        Slot s;
         SkinnyParams q = base_params(B, 2 * D, EPI_GATE);
+        if (j == 1) add_gather(q, p->emb.f(), D, tok + (size_t)r * 2 + 0, (long)Htot * 2, D);
+        q.W = p->wh[0]->f();
         q.ldw = 2 * D;
-        if (l == 0) {   // mask 'A': only the column to the left, i.e. the embedding of the code just sampled
-            if (j == 1) add_gather(q, p->emb.f(), D, tok + (size_t)r * 2 + 0, (long)Htot * 2, D);
-            q.W = p->wh[0]->f();               // tap 0 block
-        } else if (j == 0) {
-            add_dense(q, XH(l, 0), D, 0, D);
-            q.W = p->wh[l]->f() + D;           // tap 1 block (the column itself)
-        } else {
-            add_dense(q, XH(l, 0), D, 0, D);
-            add_dense(q, XH(l, 1), D, 0, D);
-            q.W = p->wh[l]->f();
-        }
-        q.bias = p->bh[l]->f();
-        q.add1 = V2H(l) + (size_t)j * 2 * D;
+        q.bias = p->bh[0]->f();
+        q.add1 = V2H(0);
         q.add1_stride = 4 * D;
-        q.clsrow = CR(l);
+        q.clsrow = CR(0);
         q.cls_ld = 2 * D;
         q.gateD = D;
-        q.out = w->G.f();
+        q.out = G(0);
         q.out_stride = D;
-        push(q);
-
-        SkinnyParams h = base_params(B, D, EPI_LINEAR);
-        add_dense(h, w->G.f(), D, 0, D);
-        h.W = p->wr[l]->f();
-        h.ldw = D;
-        h.bias = p->br[l]->f();
-        if (l == 0) {
-            h.out = w->OH0.f();
-        } else {
-            h.add1 = XH(l, j);
-            h.add1_stride = D;
-            h.out = XH(l + 1, j);
-        }
-        h.out_stride = D;
-        push(h);
-
-        if (l == 0 && NL > 1) {
-            SkinnyParams f = base_params(B, D, EPI_LINEAR);
-            add_dense(f, w->OH0.f(), D, 0, D);
-            f.W = p->fha.f();
-            f.ldw = D;
-            f.add1 = w->AEH.f() + (size_t)r * D;
-            f.add1_stride = (long)Htot * D;
-            f.out = XH(1, j);
-            f.out_stride = D;
-            push(f);
-        }
+        s.add(q);
+        out.push_back(s);
     }
-    const float *xfin = NL > 1 ? XH(NL, j) : w->OH0.f();
-    SkinnyParams h1 = base_params(B, p->HID, EPI_LINEAR);
-    add_dense(h1, xfin, D, 0, D);
-    h1.W = p->w1.f();
-    h1.ldw = D;
-    h1.bias = p->b1.f();
-    h1.relu = 1;
-    h1.out = w->Y.f();
-    h1.out_stride = p->HID;
-    push(h1);
+    for (int l = 1; l < NL; ++l) {   // S_l
+        Slot s;
+        SkinnyParams a = base_params(B, D, EPI_LINEAR);
+        add_dense(a, G(l - 1), D, 0, D);
+        a.W = p->rw[l]->f();
+        a.ldw = D;
+        a.bias = p->rb[l]->f();
+        if (l == 1) {
+            a.add1 = w->AEH.f() + (size_t)r * D;
+            a.add1_stride = (long)Htot * D;
+        } else {
+            a.add1 = XH(l - 1, j);
+            a.add1_stride = D;
+        }
+        a.out = XH(l, j);
+        a.out_stride = D;
+        s.add(a);
 
-    SkinnyParams h2 = base_params(B, p->V, EPI_LINEAR);
-    add_dense(h2, w->Y.f(), p->HID, 0, p->HID);
-    h2.W = p->w2.f();
-    h2.ldw = p->HID;
-    h2.bias = p->b2.f();
-    h2.out = w->LG.f();
-    h2.out_stride = p->V;
-    push(h2);
+        SkinnyParams g = base_params(B, 2 * D, EPI_GATE);
+        add_dense(g, G(l - 1), D, 0, D);
+        if (l >= 2) add_dense(g, XH(l - 1, j), D, 0, D);
+        g.W = p->wB[l]->f();
+        g.ldw = g.Ktot;
+        g.bias = p->bm[l]->f();
+        g.add1 = V2H(l);
+        g.add1_stride = 4 * D;
+        if (l == 1) {
+            g.add2 = w->AEH1.f() + (size_t)r * 2 * D;
+            g.add2_stride = (long)Htot * 2 * D;
+        }
+        if (j == 1) {
+            g.add3 = T0(l);
+            g.add3_stride = 2 * D;
+        }
+        g.clsrow = CR(l);
+        g.cls_ld = 2 * D;
+        g.gateD = D;
+        g.out = G(l);
+        g.out_stride = D;
+        s.add(g);
+        if (j == 0 && l >= 2) s.add(make_t0(l - 1));
+        out.push_back(s);
+    }
+    {   // head1' = relu(output_conv.0(XH_NL)) with XH_NL = horiz_resid_{NL-1}(G_{NL-1}) + XH_{NL-1} composed in
+        Slot s;
+        SkinnyParams h1 = base_params(B, p->HID, EPI_LINEAR);
+        add_dense(h1, G(NL - 1), D, 0, D);
+        if (NL >= 2) add_dense(h1, XH(NL - 1, j), D, 0, D);
+        h1.W = p->w1m.f();
+        h1.ldw = h1.Ktot;
+        h1.bias = p->b1m.f();
+        h1.relu = 1;
+        h1.out = w->Y.f();
+        h1.out_stride = p->HID;
+        s.add(h1);
+        if (j == 0 && NL >= 2) s.add(make_t0(NL - 1));
+        out.push_back(s);
+    }
+    {
+        Slot s;
+        SkinnyParams h2 = base_params(B, p->V, EPI_LINEAR);
+        add_dense(h2, w->Y.f(), p->HID, 0, p->HID);
+        h2.W = p->w2.f();
+        h2.ldw = p->HID;
+        h2.bias = p->b2.f();
+        h2.out = w->LG.f();
+        h2.out_stride = p->V;
+        s.add(h2);
+        out.push_back(s);
+    }
 }
 
 int launch_sampler(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s) {
@@ -413,9 +451,10 @@ int run_row(ts_pixelcnn *p, const RunCfg &c, int r, bool need_h, hipStream_t s) 
     build_horizontal(p, c, r, 0, H);
     size_t vi = 0;
     if (p->pair_vh) {
-        // V0, V1 alone (hg_0 needs V2H_0); then V_k rides with the (k-2)-th stage of column 0
+        // hg_0 needs V2H_0 (V1); S_k needs V2H_k (V_{k+2}): V0, V1 | H0 + V2 | V3 | H1 + V4 | H2 + V5 | ...
         for (; vi < 2 && vi < V.size(); ++vi) TS_TRY(launch_slot(ctx, V[vi], nullptr, s));
         for (size_t k = 0; k < H.size(); ++k) {
+            if (k == 1 && vi < V.size()) TS_TRY(launch_slot(ctx, V[vi++], nullptr, s));
             const Slot *ride = nullptr;
             if (vi < V.size() && V[vi].n + H[k].n <= SKINNY_MAX_PROBLEMS) ride = &V[vi++];
             TS_TRY(launch_slot(ctx, H[k], ride, s));
@@ -523,6 +562,98 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
     TS_TRY(p->b1.upload(b1, (size_t)p->HID * sizeof(float)));
     TS_TRY(p->w2.upload(w2, (size_t)V * p->HID * sizeof(float)));
     TS_TRY(p->b2.upload(b2, (size_t)V * sizeof(float)));
+    // ---- composed horizontal maps (products in double, rounded once) ----
+    {
+        auto mat = [&](const std::string &k, int rows_, int cols_, int stride_, int off_) {   // rows_ x cols_ view of a conv weight
+            const float *src = sd.m.at(k)->data;
+            std::vector<double> m((size_t)rows_ * cols_);
+            for (int i = 0; i < rows_; ++i)
+                for (int jx = 0; jx < cols_; ++jx) m[(size_t)i * cols_ + jx] = src[((size_t)i * cols_ + jx) * stride_ + off_];
+            return m;
+        };
+        auto vec = [&](const std::string &k, int n_) {
+            const float *src = sd.m.at(k)->data;
+            return std::vector<double>(src, src + n_);
+        };
+        auto mm = [](const std::vector<double> &A, const std::vector<double> &Bm, int m_, int k_, int n_) {   // (m x k)(k x n)
+            std::vector<double> Cm((size_t)m_ * n_, 0.0);
+            for (int i = 0; i < m_; ++i)
+                for (int kk = 0; kk < k_; ++kk) {
+                    const double a = A[(size_t)i * k_ + kk];
+                    const double *brow = &Bm[(size_t)kk * n_];
+                    double *crow = &Cm[(size_t)i * n_];
+                    for (int jx = 0; jx < n_; ++jx) crow[jx] += a * brow[jx];
+                }
+            return Cm;
+        };
+        auto mv = [](const std::vector<double> &A, const std::vector<double> &x, int m_, int k_) {
+            std::vector<double> y(m_, 0.0);
+            for (int i = 0; i < m_; ++i)
+                for (int kk = 0; kk < k_; ++kk) y[i] += A[(size_t)i * k_ + kk] * x[kk];
+            return y;
+        };
+        auto upf = [&](std::vector<std::unique_ptr<DevBuf>> &dst, const std::vector<double> &v) {
+            return upload_vec(dst, std::vector<float>(v.begin(), v.end()));
+        };
+        // entry 0 of the per-layer vectors is a placeholder (layer 0 has no composed stage)
+        TS_TRY(upload_vec(p->rw, std::vector<float>(1, 0.f)));
+        TS_TRY(upload_vec(p->rb, std::vector<float>(1, 0.f)));
+        TS_TRY(upload_vec(p->wB, std::vector<float>(1, 0.f)));
+        TS_TRY(upload_vec(p->bm, std::vector<float>(1, 0.f)));
+        const std::vector<double> Fha = [&] {   // fusion_h[:, :D]
+            const float *src = sd.m.at("fusion_h.weight")->data;
+            std::vector<double> m((size_t)D * D);
+            for (int i = 0; i < D; ++i)
+                for (int jx = 0; jx < D; ++jx) m[(size_t)i * D + jx] = src[(size_t)i * D2 + jx];
+            return m;
+        }();
+        for (int l = 1; l < NL; ++l) {
+            const std::string q = "layers." + std::to_string(l), qp = "layers." + std::to_string(l - 1);
+            std::vector<double> Rw = mat(qp + ".horiz_resid.weight", D, D, 1, 0), rbv = vec(qp + ".horiz_resid.bias", D);
+            if (l == 1) {   // XH_1 = fusion_h[:, :D] . (horiz_resid_0 . G_0 + b) + AEH
+                rbv = mv(Fha, rbv, D, D);
+                Rw = mm(Fha, Rw, D, D, D);
+            }
+            const std::vector<double> Wh1 = mat(q + ".horiz_stack.weight", D2, D, 2, 1);   // tap 1: the column itself
+            const std::vector<double> Wm = mm(Wh1, Rw, D2, D, D);
+            std::vector<double> bmv = mv(Wh1, rbv, D2, D);
+            const std::vector<double> bhv = vec(q + ".horiz_stack.bias", D2);
+            for (int i = 0; i < D2; ++i) bmv[i] += bhv[i];
+            const int KB = l == 1 ? D : 2 * D;
+            std::vector<double> WB((size_t)D2 * KB);
+            for (int i = 0; i < D2; ++i) {
+                for (int jx = 0; jx < D; ++jx) WB[(size_t)i * KB + jx] = Wm[(size_t)i * D + jx];
+                if (l >= 2)
+                    for (int jx = 0; jx < D; ++jx) WB[(size_t)i * KB + D + jx] = Wh1[(size_t)i * D + jx];
+            }
+            TS_TRY(upf(p->rw, Rw));
+            TS_TRY(upf(p->rb, rbv));
+            TS_TRY(upf(p->wB, WB));
+            TS_TRY(upf(p->bm, bmv));
+            if (l == 1) {
+                std::vector<float> wh1f(Wh1.begin(), Wh1.end());
+                TS_TRY(pack_linear_layer(wh1f.data(), D, nullptr, D2, D, &p->aud_h1));
+            }
+        }
+        {   // head1' = relu(W1 . (horiz_resid_{NL-1} . G + b + XH_{NL-1}) + b1)
+            const std::string ql = "layers." + std::to_string(NL - 1);
+            const std::vector<double> W1 = mat("output_conv.0.weight", p->HID, D, 1, 0);
+            const std::vector<double> Wr = mat(ql + ".horiz_resid.weight", D, D, 1, 0);
+            const std::vector<double> W1r = mm(W1, Wr, p->HID, D, D);
+            std::vector<double> bb = mv(W1, vec(ql + ".horiz_resid.bias", D), p->HID, D);
+            const std::vector<double> b1v = vec("output_conv.0.bias", p->HID);
+            for (int i = 0; i < p->HID; ++i) bb[i] += b1v[i];
+            const int K1 = NL >= 2 ? 2 * D : D;
+            std::vector<float> wm((size_t)p->HID * K1), bf(bb.begin(), bb.end());
+            for (int i = 0; i < p->HID; ++i) {
+                for (int jx = 0; jx < D; ++jx) wm[(size_t)i * K1 + jx] = (float)W1r[(size_t)i * D + jx];
+                if (NL >= 2)
+                    for (int jx = 0; jx < D; ++jx) wm[(size_t)i * K1 + D + jx] = (float)W1[(size_t)i * D + jx];
+            }
+            TS_TRY(p->w1m.upload(wm.data(), wm.size() * sizeof(float)));
+            TS_TRY(p->b1m.upload(bf.data(), bf.size() * sizeof(float)));
+        }
+    }
     if (const char *e = std::getenv("TS_NO_GRAPH")) p->use_graph = !(e[0] && e[0] != '0');
     if (const char *e = std::getenv("TS_NO_PAIR")) p->pair_vh = !(e[0] && e[0] != '0');
     *out = p.release();
@@ -583,6 +714,10 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
         TS_TRY(run_conv(ctx, q, 0, s));
         conv_layer_params(p->aud_fh, w->AE.f(), D, 1, B * Htot, nullptr, 0, w->AEH.f(), D, 0, D, &q);
         TS_TRY(run_conv(ctx, q, 0, s));
+        if (NL > 1) {   // layer 1's horiz_stack applied to the audio term of XH_1, for every row at once
+            conv_layer_params(p->aud_h1, w->AEH.f(), D, 1, B * Htot, nullptr, 0, w->AEH1.f(), 2 * D, 0, 2 * D, &q);
+            TS_TRY(run_conv(ctx, q, 0, s));
+        }
     }
     {
         MiscScope ms(ctx, s);

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(W * 64) void skinny_gemm_kernel(const SkinnyBatch b
         if (p.bias) a += p.bias[nc];
         if (p.add1) a += p.add1[(long)(rowc >> p.add1_shift) * p.add1_stride + nc];
         if (p.add2) a += p.add2[(long)(rowc >> p.add2_shift) * p.add2_stride + nc];
+        if (p.add3) a += p.add3[(long)rowc * p.add3_stride + nc];
         e_add[rr] = a;
         e_cls[rr] = (p.epi == EPI_GATE && p.clsrow) ? p.clsrow[(long)rowc * p.cls_ld + (nc % p.cls_ld)] : 0.f;
     }
