@@ -358,3 +358,53 @@ def test_face_full_length_vs_oracle(hip):
     assert torch.equal(solo[0], out[1])
     ref = FO.face_generator(wav[:1], ids[:1], sd, 300)
     np.testing.assert_allclose(out[:1].cpu().numpy(), ref, atol=1e-4, rtol=0)
+
+
+# ----------------------------------------------------------------------------------------------- ragged / odd sizes
+def test_ragged_lengths_and_batches(hip):
+    """Edge cases the reference's shapes allow: clip lengths that are not multiples of 4 (odd length entering the second
+    stride-2 conv), a single clip, and a batch that does not fill / overflows one 32-row MFMA tile — all vs the oracle."""
+    from talkshow_amd import _lib
+    from talkshow_amd.modules import AudioEncoder, GatedPixelCNN, VQVAE
+    dims = dict(input_dim=128, dim=64, n_layers=3)
+    sd_v = synth.vqvae_state_dict(seed=9, in_dim=39, num_embeddings=128, num_hiddens=128)
+    vq = VQVAE(39, 64, 128, 128, 2).cuda(); vq.load_state_dict(synth.to_torch(sd_v))
+    for B, T in [(1, 78), (3, 31), (2, 4)]:
+        poses = synth.gt_poses(50 + T, B, T, dim=39)
+        z, q, lat = vq.encode_nlc(poses, want_z=True)
+        zr, er, ir = O.vqvae_encode(poses, sd_v)
+        np.testing.assert_allclose(z.cpu().numpy().transpose(0, 2, 1), zr, atol=2e-5, rtol=0)
+        np.testing.assert_array_equal(lat.cpu().numpy(), ir)
+        rec = vq.decode_nlc(lat)
+        assert rec.shape == (B, 4 * (T // 4), 39)
+        np.testing.assert_allclose(rec.cpu().numpy().transpose(0, 2, 1), O.vqvae_decode(ir, sd_v), atol=1e-4, rtol=0)
+    sd_a = synth.audioencoder_state_dict(seed=9)
+    ae = AudioEncoder(64, 256, 2).cuda(); ae.load_state_dict(synth.to_torch(sd_a))
+    mf = synth.mfcc_features(60, 2, 79)
+    np.testing.assert_allclose(ae.forward_nlc(mf).cpu().numpy().transpose(0, 2, 1),
+                               O.audio_encoder(np.ascontiguousarray(mf.transpose(0, 2, 1)), sd_a), atol=2e-5, rtol=0)
+    sd_p = synth.pixelcnn_state_dict(seed=9, **dims)
+    px = GatedPixelCNN(dims["input_dim"], dims["dim"], dims["n_layers"], 4, True, True).cuda()
+    px.load_state_dict(synth.to_torch(sd_p))
+    for B, H in [(1, 1), (33, 4), (5, 2)]:          # H = 1: no row above at all; B = 33: two MFMA row tiles
+        rng = np.random.default_rng(B * 10 + H)
+        aud = rng.standard_normal((B, H, 256)).astype(np.float32)
+        label = synth.speaker_ids(B)
+        codes, _ = px.run(label, aud, mode=_lib.TS_SAMPLE_GREEDY)
+        ref = O.pixelcnn_generate(label, np.repeat(aud.transpose(0, 2, 1)[:, :, :, None], 2, axis=3), sd_p, dims["n_layers"], H)
+        np.testing.assert_array_equal(codes.cpu().numpy(), ref)
+
+
+def test_single_layer_pixelcnn(hip):
+    """n_layers = 1: no audio fusion, no composed stage (the launch plan's degenerate branch)."""
+    from talkshow_amd import _lib
+    from talkshow_amd.modules import GatedPixelCNN
+    sd = synth.pixelcnn_state_dict(seed=4, input_dim=64, dim=32, n_layers=1)
+    px = GatedPixelCNN(64, 32, 1, 4, True, True).cuda(); px.load_state_dict(synth.to_torch(sd))
+    rng = np.random.default_rng(1)
+    aud = rng.standard_normal((2, 5, 256)).astype(np.float32)
+    label = synth.speaker_ids(2)
+    codes, logits = px.run(label, aud, mode=_lib.TS_SAMPLE_GREEDY, want_logits=True)
+    ref, rl = O.pixelcnn_generate(label, np.repeat(aud.transpose(0, 2, 1)[:, :, :, None], 2, axis=3), sd, 1, 5, return_logits=True)
+    np.testing.assert_allclose(logits.cpu().numpy(), rl, atol=3e-4, rtol=0)
+    np.testing.assert_array_equal(codes.cpu().numpy(), ref)
