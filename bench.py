@@ -196,10 +196,7 @@ def main():
     H = T // 4
     S = max(1, a.streams)
     streams = _lib.create_streams(S, local)
-    lat_b = [torch.empty((B, H), dtype=torch.int64, device=dev) for _ in range(S)]
-    lat_h = [torch.empty((B, H), dtype=torch.int64, device=dev) for _ in range(S)]
-    gt_body = [g[..., :39].contiguous() for g in gt]
-    gt_hand = [g[..., 39:].contiguous() for g in gt]
+    gt_codes = [torch.empty((B, H, 2), dtype=torch.int64, device=dev) for _ in range(S)]
 
     def step(k):
         # one complete pass over one batch of 32 clips, enqueued on stream k % S (the library keeps one scratch arena
@@ -207,8 +204,8 @@ def main():
         with torch.cuda.stream(streams[k % S]):
             s = _lib.stream_ptr()
             # VQ-VAE encode half of configs[1] (VQVAE.encode of the 300 GT frames, body and hand)
-            _lib.check(lib.ts_vqvae_encode(w.g_body.handle(), _lib.dptr(gt_body[k % NB]), B, T, None, _lib.dptr(lat_b[k % S]), None, s))
-            _lib.check(lib.ts_vqvae_encode(w.g_hand.handle(), _lib.dptr(gt_hand[k % NB]), B, T, None, _lib.dptr(lat_h[k % S]), None, s))
+            _lib.check(lib.ts_body_vq_infer(w.g_body.handle(), w.g_hand.handle(), _lib.dptr(gt[k % NB]), B, T,
+                                            _lib.dptr(gt_codes[k % S]), None, s))
             # audio encoder -> PixelCNN greedy -> VQ decode
             return w.generate_batch(mfcc[k % NB], ids, mode=_lib.TS_SAMPLE_GREEDY, clip_index0=rank * B)
 

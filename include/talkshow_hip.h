@@ -75,6 +75,10 @@ int ts_vqvae_encode(ts_vqvae *vq, const float *poses_dev, int B, int T, float *z
  * the two halves of one (B,4H,129) buffer — the torch.cat of smplx_body_pixel.py:285). */
 int ts_vqvae_decode(ts_vqvae *vq, const int64_t *latents_dev, int B, int H, float *out_dev, int out_ld,
                     int out_col0, void *stream);
+/* body + hand decode in lockstep into one (B,4H,body_dim+hand_dim) buffer (the two decode calls + torch.cat of
+ * smplx_body_pixel.py:282-285). */
+int ts_vqvae_decode_pair(ts_vqvae *vq_body, ts_vqvae *vq_hand, const int64_t *lat_body_dev, const int64_t *lat_hand_dev,
+                         int B, int H, float *out_dev, void *stream);
 /* VQVAE.forward, eval branch (vqvae_1d.py:184-189): encode -> quantise -> decode in one call. */
 int ts_vqvae_forward(ts_vqvae *vq, const float *poses_dev, int B, int T, int64_t *latents_dev, float *out_dev,
                      int out_ld, int out_col0, void *stream);
@@ -129,7 +133,10 @@ int ts_body_pixel_infer(ts_convnet *audioenc, ts_pixelcnn *pix, ts_vqvae *vq_bod
                         const float *uniforms_dev, uint64_t seed, int64_t clip_index0, int64_t *codes_dev,
                         float *poses_dev, void *stream);
 /* s2g_body_vq.TrainWrapper.infer_on_audio(initial_pose=gt) core (smplx_body_vq.py:254-281):
- * poses_dev (B,T,body_dim+hand_dim) in c_index order -> recon_dev same shape, codes_dev (B,H,2) int64. */
+ * poses_dev (B,T,body_dim+hand_dim) in c_index order -> recon_dev same shape, codes_dev (B,H,2) int64.
+ * Either output may be NULL: recon_dev == NULL is the encode-only form (VQVAE.encode of both parts, the latents
+ * `s2g_body_pixel.__call__` builds, smplx_body_pixel.py:193-203).  Body and hand networks run in lockstep
+ * (same-shape layers go out as one grouped launch). */
 int ts_body_vq_infer(ts_vqvae *vq_body, ts_vqvae *vq_hand, const float *poses_dev, int B, int T,
                      int64_t *codes_dev, float *recon_dev, void *stream);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ts_vqvae_destroy": (None, [_vp]),
     "ts_vqvae_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ts_vqvae_decode": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "ts_vqvae_decode_pair": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ts_vqvae_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
     "ts_pixelcnn_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ts_pixelcnn_destroy": (None, [_vp]),

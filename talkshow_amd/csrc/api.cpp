@@ -55,10 +55,9 @@ int ts_body_pixel_infer(ts_convnet *ae, ts_pixelcnn *pix, ts_vqvae *vb, ts_vqvae
         TS_HIP(hipMemcpy2DAsync(w.lat[k].p, sizeof(int64_t), codes + k, 2 * sizeof(int64_t), sizeof(int64_t),
                                 (size_t)B * H, hipMemcpyDeviceToDevice, s));
     }
-    const int ld = body_dim + hand_dim;
-    TS_TRY(ts_vqvae_decode(vb, static_cast<int64_t *>(w.lat[0].p), B, H, poses, ld, 0, s));
-    TS_TRY(ts_vqvae_decode(vh, static_cast<int64_t *>(w.lat[1].p), B, H, poses, ld, body_dim, s));
-    return 0;
+    (void)body_dim;
+    (void)hand_dim;
+    return ts_vqvae_decode_pair(vb, vh, static_cast<int64_t *>(w.lat[0].p), static_cast<int64_t *>(w.lat[1].p), B, H, poses, s);
 }
 
 int ts_op_conv1d(ts_ctx *ctx, const float *x, int B, int Lin, int Cin, const float *w, const float *bias, int Cout,

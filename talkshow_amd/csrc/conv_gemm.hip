@@ -179,12 +179,20 @@ double conv_gemm_flops(const ConvParams &p) { return 2.0 * p.M * (double)p.N * p
 
 
 static int pick_tile(const ConvParams &p) {
-    // Prefer the large tile when it alone fills the chip; otherwise smaller tiles so that the tile count is
-    // >> 256 CUs and the hardware dispatcher can balance the tail (MI355X_MICROARCH: 256 CUs, 8 XCDs).
-    auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ngroups; };
-    if (tiles(128, 128) >= 2 * 256) return 1;
-    if (p.N <= 64 || tiles(128, 64) < 256) return 2;
-    return tiles(128, 64) >= 2 * 256 ? 3 : 2;
+    // Cost model: the 256 CUs pull tiles dynamically, so a launch lasts about ceil(tiles / 256) tile-times on the busiest
+    // CU; a tile-time is its MACs over the tile shape's measured intrinsic efficiency (tools/tune_conv.py on 4096^3:
+    // 128x128 125 TF, 64x128 116, 128x64 112, 64x64 111).  Small / mid-size layers want many small tiles (tail), big ones
+    // the 128x128 tile (half the L2->LDS traffic per MAC).
+    struct Cand { int id, bm, bn; double eff; };
+    static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.89}, {3, 128, 64, 0.90}, {4, 64, 128, 0.93}};
+    int best = 2;
+    double best_cost = 1e300;
+    for (const Cand &c : cands) {
+        const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * p.ngroups;
+        const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
+        if (cost < best_cost) { best_cost = cost; best = c.id; }
+    }
+    return best;
 }
 
 hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream) {

@@ -336,65 +336,121 @@ int pack_trunk(ts_ctx *ctx, const StateDict &sd, const std::string &p, int in_di
     return 0;
 }
 
-// runs one layer pool[in] -> pool[out]
-int run_layer(ts_ctx *ctx, const ConvLayer &L, const float *x, int ldx, int B, int Lin, const float *res, int ldr,
-              float *out, int ldo, int col0, int nstore, hipStream_t s, int *Lout) {
-    ConvParams p;
-    *Lout = conv_layer_params(L, x, ldx, B, Lin, res, ldr, out, ldo, col0, nstore, &p);
-    return run_conv(ctx, p, 0, s);
+// Runs the same layer of n (1 or 2) structurally identical networks.  Body and hand VQ-VAEs differ only in their weights
+// (and in the width of their first / last layer), so wherever the two layers have the same geometry they go out as ONE
+// grouped conv_gemm launch (blockIdx.z selects the network): twice the tiles per launch, which is what the 256 CUs need
+// at these sizes (608 tiles of 64x64 per network leave a 21 % tail; 1216 leave 5 %).
+int run_layer_n(ts_ctx *ctx, int n, const ConvLayer *const *L, const float *const *x, int ldx, int B, int Lin,
+                const float *const *res, int ldr, float *const *out, int ldo, const int *col0, const int *nstore,
+                hipStream_t s, int *Lout) {
+    ConvParams p[2];
+    for (int i = 0; i < n; ++i)
+        *Lout = conv_layer_params(*L[i], x[i], ldx, B, Lin, res ? res[i] : nullptr, ldr, out[i], ldo, col0 ? col0[i] : 0,
+                                  nstore[i], &p[i]);
+    bool same = n == 2 && L[0]->kind == L[1]->kind && L[0]->cin_pad == L[1]->cin_pad && L[0]->ktot == L[1]->ktot &&
+                L[0]->act == L[1]->act && L[0]->ngroups == L[1]->ngroups && nstore[0] == nstore[1] &&
+                2 * L[0]->ngroups <= 4;
+    if (same) {
+        ConvParams &q = p[0];
+        for (int g = 0; g < L[1]->ngroups; ++g) q.g[q.ngroups + g] = p[1].g[g];
+        q.ngroups += L[1]->ngroups;
+        return run_conv(ctx, q, 0, s);
+    }
+    for (int i = 0; i < n; ++i) TS_TRY(run_conv(ctx, p[i], 0, s));
+    return 0;
 }
 
-// Res_CNR_Stack on pool buffer `cur`; returns the index of the output buffer
-int run_stack(ts_ctx *ctx, const Stack &st, Pool &pool, int cur, int c, int B, int L, hipStream_t s, int *out_idx) {
+int run_layer(ts_ctx *ctx, const ConvLayer &L, const float *x, int ldx, int B, int Lin, const float *res, int ldr,
+              float *out, int ldo, int col0, int nstore, hipStream_t s, int *Lout) {
+    const ConvLayer *Lp[1] = {&L};
+    const float *xp[1] = {x}, *rp[1] = {res};
+    float *op[1] = {out};
+    return run_layer_n(ctx, 1, Lp, xp, ldx, B, Lin, rp, ldr, op, ldo, &col0, &nstore, s, Lout);
+}
+
+// Res_CNR_Stack on pool buffer `cur` of each network; returns the index of the output buffer (same for all)
+int run_stack_n(ts_ctx *ctx, int n, const Stack *const *st, Pool *const *pool, int cur, int c, int B, int L, hipStream_t s,
+                int *out_idx) {
     int h = cur, tmp = 0;
-    for (auto &l : st.layers) {
-        const int o = pool.pick(cur, h);
-        TS_TRY(run_layer(ctx, *l, pool.buf(h), c, B, L, nullptr, 0, pool.buf(o), c, 0, c, s, &tmp));
+    const int ns[2] = {c, c};
+    const ConvLayer *Lp[2];
+    const float *xp[2], *rp[2];
+    float *op[2];
+    for (size_t k = 0; k < st[0]->layers.size(); ++k) {
+        const int o = pool[0]->pick(cur, h);
+        for (int i = 0; i < n; ++i) { Lp[i] = st[i]->layers[k].get(); xp[i] = pool[i]->buf(h); op[i] = pool[i]->buf(o); }
+        TS_TRY(run_layer_n(ctx, n, Lp, xp, c, B, L, nullptr, 0, op, c, nullptr, ns, s, &tmp));
         h = o;
     }
-    const int o = pool.pick(cur, h);
-    TS_TRY(run_layer(ctx, st.tail, pool.buf(h), c, B, L, pool.buf(cur), c, pool.buf(o), c, 0, c, s, &tmp));
+    const int o = pool[0]->pick(cur, h);
+    for (int i = 0; i < n; ++i) { Lp[i] = &st[i]->tail; xp[i] = pool[i]->buf(h); rp[i] = pool[i]->buf(cur); op[i] = pool[i]->buf(o); }
+    TS_TRY(run_layer_n(ctx, n, Lp, xp, c, B, L, rp, c, op, c, nullptr, ns, s, &tmp));
     *out_idx = o;
     return 0;
 }
 
-// encoder trunk: x (B,T,in_dim) with row stride x_ld (0 = in_dim) -> pool buffer holding (B,T/4,hid); returns buffer
-// index and H
-int run_trunk(ts_convnet *n, const float *x, int x_ld, int B, int T, hipStream_t s, int *out_idx, int *H) {
+// encoder trunks of n networks: x[i] (B,T,in_dim_i) with row stride x_ld (0 = in_dim) -> pool buffer holding
+// (B,T/4,hid); returns buffer index (same for all) and H
+int run_trunk_n(int n, ts_convnet *const *net, const float *const *x, int x_ld, int B, int T, hipStream_t s, int *out_idx,
+                int *H) {
     if (T < 4) return fail("sequence too short: need T >= 4 frames");
-    ts_ctx *ctx = n->ctx;
-    const int hid = n->hid;
-    ts_convnet::Work &wk = n->work(s);
-    Pool &pool = wk.pool;
-    TS_TRY(pool.ensure((size_t)B * T * (hid / 4)));
-    const float *xin = x;
-    int ldx = n->in_dim;
-    if (n->in_dim % 32 != 0) {
-        const int cp = n->project.cin_pad;
-        TS_TRY(wk.xin.ensure((size_t)B * T * cp * sizeof(float)));
-        MiscScope ms(ctx, s);
-        TS_HIP(launch_pad_rows(x, x_ld > 0 ? x_ld : n->in_dim, n->in_dim, wk.xin.f(), cp, cp, (long)B * T, s));
-        xin = wk.xin.f();
-        ldx = cp;
-    } else if (x_ld > 0) {
-        ldx = x_ld;
+    ts_ctx *ctx = net[0]->ctx;
+    const int hid = net[0]->hid;
+    Pool *pool[2];
+    const float *xin[2];
+    int ldx[2];
+    for (int i = 0; i < n; ++i) {
+        if (net[i]->hid != hid) return fail("paired networks must have the same width");
+        ts_convnet::Work &wk = net[i]->work(s);
+        pool[i] = &wk.pool;
+        TS_TRY(pool[i]->ensure((size_t)B * T * (hid / 4)));
+        xin[i] = x[i];
+        ldx[i] = net[i]->in_dim;
+        if (net[i]->in_dim % 32 != 0) {
+            const int cp = net[i]->project.cin_pad;
+            TS_TRY(wk.xin.ensure((size_t)B * T * cp * sizeof(float)));
+            MiscScope ms(ctx, s);
+            TS_HIP(launch_pad_rows(x[i], x_ld > 0 ? x_ld : net[i]->in_dim, net[i]->in_dim, wk.xin.f(), cp, cp, (long)B * T, s));
+            xin[i] = wk.xin.f();
+            ldx[i] = cp;
+        } else if (x_ld > 0) {
+            ldx[i] = x_ld;
+        }
     }
     int L = T, tmp = 0, cur = 0, o = 0;
-    TS_TRY(run_layer(ctx, n->project, xin, ldx, B, L, nullptr, 0, pool.buf(0), hid / 4, 0, hid / 4, s, &tmp));
-    TS_TRY(run_stack(ctx, n->s1, pool, cur, hid / 4, B, L, s, &o));
+    const ConvLayer *Lp[2];
+    const Stack *Sp[2];
+    const float *xp[2];
+    float *op[2];
+    int ns[2];
+    // first layer: input widths differ between body and hand (39 / 90 channels) -> separate launches
+    for (int i = 0; i < n; ++i)
+        TS_TRY(run_layer(ctx, net[i]->project, xin[i], ldx[i], B, L, nullptr, 0, pool[i]->buf(0), hid / 4, 0, hid / 4, s, &tmp));
+    for (int i = 0; i < n; ++i) Sp[i] = &net[i]->s1;
+    TS_TRY(run_stack_n(ctx, n, Sp, pool, cur, hid / 4, B, L, s, &o));
     cur = o;
-    o = pool.pick(cur);
-    TS_TRY(run_layer(ctx, n->down1, pool.buf(cur), hid / 4, B, L, nullptr, 0, pool.buf(o), hid / 2, 0, hid / 2, s, &L));
+    o = pool[0]->pick(cur);
+    for (int i = 0; i < n; ++i) { Lp[i] = &net[i]->down1; xp[i] = pool[i]->buf(cur); op[i] = pool[i]->buf(o); ns[i] = hid / 2; }
+    TS_TRY(run_layer_n(ctx, n, Lp, xp, hid / 4, B, L, nullptr, 0, op, hid / 2, nullptr, ns, s, &L));
     cur = o;
-    TS_TRY(run_stack(ctx, n->s2, pool, cur, hid / 2, B, L, s, &o));
+    for (int i = 0; i < n; ++i) Sp[i] = &net[i]->s2;
+    TS_TRY(run_stack_n(ctx, n, Sp, pool, cur, hid / 2, B, L, s, &o));
     cur = o;
-    o = pool.pick(cur);
-    TS_TRY(run_layer(ctx, n->down2, pool.buf(cur), hid / 2, B, L, nullptr, 0, pool.buf(o), hid, 0, hid, s, &L));
+    o = pool[0]->pick(cur);
+    for (int i = 0; i < n; ++i) { Lp[i] = &net[i]->down2; xp[i] = pool[i]->buf(cur); op[i] = pool[i]->buf(o); ns[i] = hid; }
+    TS_TRY(run_layer_n(ctx, n, Lp, xp, hid / 2, B, L, nullptr, 0, op, hid, nullptr, ns, s, &L));
     cur = o;
-    TS_TRY(run_stack(ctx, n->s3, pool, cur, hid, B, L, s, &o));
+    for (int i = 0; i < n; ++i) Sp[i] = &net[i]->s3;
+    TS_TRY(run_stack_n(ctx, n, Sp, pool, cur, hid, B, L, s, &o));
     *out_idx = o;
     *H = L;
     return 0;
+}
+
+int run_trunk(ts_convnet *n, const float *x, int x_ld, int B, int T, hipStream_t s, int *out_idx, int *H) {
+    ts_convnet *np[1] = {n};
+    const float *xp[1] = {x};
+    return run_trunk_n(1, np, xp, x_ld, B, T, s, out_idx, H);
 }
 
 }  // namespace
@@ -421,48 +477,95 @@ struct ts_vqvae {
 
 namespace {
 
-int vq_encode_impl(ts_vqvae *vq, const float *poses, int poses_ld, int B, int T, float *z_out, int64_t *lat_out,
-                   float *q_out, hipStream_t s, int *Hout) {
-    ts_ctx *ctx = vq->ctx;
+// n = 1 or 2 VQ-VAEs in lockstep (body + hand): encoder trunk -> pre_vq_conv -> arg-min (-> gather)
+int vq_encode_n(int n, ts_vqvae *const *vq, const float *const *poses, int poses_ld, int B, int T, float *const *z_out,
+                int64_t *const *lat_out, float *const *q_out, hipStream_t s, int *Hout) {
+    ts_ctx *ctx = vq[0]->ctx;
     int idx = 0, H = 0, tmp = 0;
-    TS_TRY(run_trunk(&vq->enc, poses, poses_ld, B, T, s, &idx, &H));
-    ts_vqvae::Work &wk = vq->work(s);
-    TS_TRY(wk.z.ensure((size_t)B * H * vq->emb * sizeof(float)));
-    float *z = z_out ? z_out : wk.z.f();
-    TS_TRY(run_layer(ctx, vq->enc.pre_vq, vq->enc.work(s).pool.buf(idx), vq->hid, B, H, nullptr, 0, z, vq->emb, 0, vq->emb, s, &tmp));
+    ts_convnet *nets[2];
+    for (int i = 0; i < n; ++i) nets[i] = &vq[i]->enc;
+    TS_TRY(run_trunk_n(n, nets, poses, poses_ld, B, T, s, &idx, &H));
+    const ConvLayer *Lp[2];
+    const float *xp[2];
+    float *zp[2];
+    int ns[2];
+    for (int i = 0; i < n; ++i) {
+        ts_vqvae::Work &wk = vq[i]->work(s);
+        TS_TRY(wk.z.ensure((size_t)B * H * vq[i]->emb * sizeof(float)));
+        zp[i] = (z_out && z_out[i]) ? z_out[i] : wk.z.f();
+        Lp[i] = &vq[i]->enc.pre_vq;
+        xp[i] = vq[i]->enc.work(s).pool.buf(idx);
+        ns[i] = vq[i]->emb;
+    }
+    TS_TRY(run_layer_n(ctx, n, Lp, xp, vq[0]->hid, B, H, nullptr, 0, zp, vq[0]->emb, nullptr, ns, s, &tmp));
     {
         MiscScope ms(ctx, s);
-        TS_HIP(launch_vq_argmin(z, vq->emb, B * H, vq->codebook.f(), vq->code_sq.f(), vq->ncode, vq->emb, lat_out, 1, s));
-        if (q_out) TS_HIP(launch_gather_rows(vq->codebook.f(), vq->emb, lat_out, 1, B * H, vq->emb, q_out, vq->emb, s));
+        for (int i = 0; i < n; ++i) {
+            TS_HIP(launch_vq_argmin(zp[i], vq[i]->emb, B * H, vq[i]->codebook.f(), vq[i]->code_sq.f(), vq[i]->ncode, vq[i]->emb,
+                                    lat_out[i], 1, s));
+            if (q_out && q_out[i])
+                TS_HIP(launch_gather_rows(vq[i]->codebook.f(), vq[i]->emb, lat_out[i], 1, B * H, vq[i]->emb, q_out[i], vq[i]->emb, s));
+        }
     }
     *Hout = H;
     return 0;
 }
 
-int vq_decode_impl(ts_vqvae *vq, const int64_t *lat, int B, int H, float *out, int out_ld, int col0, hipStream_t s) {
-    ts_ctx *ctx = vq->ctx;
-    const int hid = vq->hid;
-    Pool &pool = vq->work(s).pool;
-    TS_TRY(pool.ensure((size_t)B * H * hid));
-    {
+int vq_encode_impl(ts_vqvae *vq, const float *poses, int poses_ld, int B, int T, float *z_out, int64_t *lat_out,
+                   float *q_out, hipStream_t s, int *Hout) {
+    ts_vqvae *vp[1] = {vq};
+    const float *pp[1] = {poses};
+    float *zp[1] = {z_out}, *qp[1] = {q_out};
+    int64_t *lp[1] = {lat_out};
+    return vq_encode_n(1, vp, pp, poses_ld, B, T, zp, lp, qp, s, Hout);
+}
+
+// n = 1 or 2 decoders in lockstep: aft_vq table gather -> stacks / up-convs -> project into out[.., col0_i .. col0_i+in_dim_i)
+int vq_decode_n(int n, ts_vqvae *const *vq, const int64_t *const *lat, int B, int H, float *out, int out_ld, const int *col0,
+                hipStream_t s) {
+    ts_ctx *ctx = vq[0]->ctx;
+    const int hid = vq[0]->hid;
+    Pool *pool[2];
+    for (int i = 0; i < n; ++i) {
+        if (vq[i]->hid != hid) return fail("paired VQ-VAEs must have the same width");
+        pool[i] = &vq[i]->work(s).pool;
+        TS_TRY(pool[i]->ensure((size_t)B * H * hid));
         MiscScope ms(ctx, s);
-        TS_HIP(launch_gather_rows(vq->aft_table.f(), hid, lat, 1, B * H, hid, pool.buf(0), hid, s));
+        TS_HIP(launch_gather_rows(vq[i]->aft_table.f(), hid, lat[i], 1, B * H, hid, pool[i]->buf(0), hid, s));
     }
     int cur = 0, o = 0, L = H;
-    TS_TRY(run_stack(ctx, vq->d1, pool, cur, hid, B, L, s, &o));
+    const ConvLayer *Lp[2];
+    const Stack *Sp[2];
+    const float *xp[2];
+    float *op[2];
+    int ns[2];
+    for (int i = 0; i < n; ++i) Sp[i] = &vq[i]->d1;
+    TS_TRY(run_stack_n(ctx, n, Sp, pool, cur, hid, B, L, s, &o));
     cur = o;
-    o = pool.pick(cur);
-    TS_TRY(run_layer(ctx, vq->up2, pool.buf(cur), hid, B, L, nullptr, 0, pool.buf(o), hid / 2, 0, hid / 2, s, &L));
+    o = pool[0]->pick(cur);
+    for (int i = 0; i < n; ++i) { Lp[i] = &vq[i]->up2; xp[i] = pool[i]->buf(cur); op[i] = pool[i]->buf(o); ns[i] = hid / 2; }
+    TS_TRY(run_layer_n(ctx, n, Lp, xp, hid, B, L, nullptr, 0, op, hid / 2, nullptr, ns, s, &L));
     cur = o;
-    TS_TRY(run_stack(ctx, vq->d2, pool, cur, hid / 2, B, L, s, &o));
+    for (int i = 0; i < n; ++i) Sp[i] = &vq[i]->d2;
+    TS_TRY(run_stack_n(ctx, n, Sp, pool, cur, hid / 2, B, L, s, &o));
     cur = o;
-    o = pool.pick(cur);
-    TS_TRY(run_layer(ctx, vq->up3, pool.buf(cur), hid / 2, B, L, nullptr, 0, pool.buf(o), hid / 4, 0, hid / 4, s, &L));
+    o = pool[0]->pick(cur);
+    for (int i = 0; i < n; ++i) { Lp[i] = &vq[i]->up3; xp[i] = pool[i]->buf(cur); op[i] = pool[i]->buf(o); ns[i] = hid / 4; }
+    TS_TRY(run_layer_n(ctx, n, Lp, xp, hid / 2, B, L, nullptr, 0, op, hid / 4, nullptr, ns, s, &L));
     cur = o;
-    TS_TRY(run_stack(ctx, vq->d3, pool, cur, hid / 4, B, L, s, &o));
+    for (int i = 0; i < n; ++i) Sp[i] = &vq[i]->d3;
+    TS_TRY(run_stack_n(ctx, n, Sp, pool, cur, hid / 4, B, L, s, &o));
     int tmp = 0;
-    TS_TRY(run_layer(ctx, vq->project, pool.buf(o), hid / 4, B, L, nullptr, 0, out, out_ld, col0, vq->in_dim, s, &tmp));
+    // last layer: output widths differ (39 / 90) -> separate launches into the two column ranges of `out`
+    for (int i = 0; i < n; ++i)
+        TS_TRY(run_layer(ctx, vq[i]->project, pool[i]->buf(o), hid / 4, B, L, nullptr, 0, out, out_ld, col0[i], vq[i]->in_dim, s, &tmp));
     return 0;
+}
+
+int vq_decode_impl(ts_vqvae *vq, const int64_t *lat, int B, int H, float *out, int out_ld, int col0, hipStream_t s) {
+    ts_vqvae *vp[1] = {vq};
+    const int64_t *lp[1] = {lat};
+    return vq_decode_n(1, vp, lp, B, H, out, out_ld, &col0, s);
 }
 
 }  // namespace
@@ -607,27 +710,42 @@ int ts_vqvae_forward(ts_vqvae *vq, const float *poses, int B, int T, int64_t *la
 
 int ts_body_vq_infer(ts_vqvae *vb, ts_vqvae *vh, const float *poses, int B, int T, int64_t *codes, float *recon,
                      void *stream) {
-    if (!vb || !vh || !poses || !recon) return fail("ts_body_vq_infer: null argument");
+    if (!vb || !vh || !poses) return fail("ts_body_vq_infer: null argument");
+    if (!codes && !recon) return fail("ts_body_vq_infer: nothing to produce");
     hipStream_t s = (hipStream_t)stream;
     const int db = vb->in_dim, dh = vh->in_dim, ld = db + dh;
-    // gt_poses[..., :each_dim[1]] / [..., each_dim[1]:] (smplx_body_vq.py:274-275): strided views of the same rows
+    // gt_poses[..., :each_dim[1]] / [..., each_dim[1]:] (smplx_body_vq.py:274-275): strided views of the same rows;
+    // body and hand networks run in lockstep (grouped launches)
     ts_vqvae *vqs[2] = {vb, vh};
-    const int off[2] = {0, db};
+    const float *pp[2] = {poses, poses + db};
+    int64_t *lp[2];
     for (int k = 0; k < 2; ++k) {
-        ts_vqvae *vq = vqs[k];
-        ts_vqvae::Work &wk = vq->work(s);
+        ts_vqvae::Work &wk = vqs[k]->work(s);
         TS_TRY(wk.lat.ensure((size_t)B * (T / 4 + 1) * sizeof(int64_t)));
-        int64_t *l = static_cast<int64_t *>(wk.lat.p);
-        int H = 0;
-        // the part's columns are a strided view of the (B,T,129) rows: the trunk pads/copies them with row stride ld
-        TS_TRY(vq_encode_impl(vq, poses + off[k], ld, B, T, nullptr, l, nullptr, s, &H));
-        TS_TRY(vq_decode_impl(vq, l, B, H, recon, ld, off[k], s));
-        if (codes) {   // codes (B,H,2): column k
-            TS_HIP(hipMemcpy2DAsync(codes + k, 2 * sizeof(int64_t), l, sizeof(int64_t), sizeof(int64_t), (size_t)B * H,
-                                    hipMemcpyDeviceToDevice, s));
-        }
+        lp[k] = static_cast<int64_t *>(wk.lat.p);
     }
+    int H = 0;
+    TS_TRY(vq_encode_n(2, vqs, pp, ld, B, T, nullptr, lp, nullptr, s, &H));
+    if (recon) {
+        const int col0[2] = {0, db};
+        const int64_t *lc[2] = {lp[0], lp[1]};
+        TS_TRY(vq_decode_n(2, vqs, lc, B, H, recon, ld, col0, s));
+    }
+    if (codes)   // codes (B,H,2): column k
+        for (int k = 0; k < 2; ++k)
+            TS_HIP(hipMemcpy2DAsync(codes + k, 2 * sizeof(int64_t), lp[k], sizeof(int64_t), sizeof(int64_t), (size_t)B * H,
+                                    hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+// VQVAE.decode of body and hand latents into the two column ranges of one (B,4H,body+hand) buffer, in lockstep
+int ts_vqvae_decode_pair(ts_vqvae *vb, ts_vqvae *vh, const int64_t *lat_body, const int64_t *lat_hand, int B, int H,
+                         float *out, void *stream) {
+    if (!vb || !vh || !lat_body || !lat_hand || !out) return fail("ts_vqvae_decode_pair: null argument");
+    ts_vqvae *vqs[2] = {vb, vh};
+    const int64_t *lc[2] = {lat_body, lat_hand};
+    const int col0[2] = {0, vb->in_dim};
+    return vq_decode_n(2, vqs, lc, B, H, out, vb->in_dim + vh->in_dim, col0, (hipStream_t)stream);
 }
 
 }  // extern "C"
