@@ -133,6 +133,8 @@ class AudioEncoder(NativeModule):
         """mfcc (B,T,in_dim) device tensor -> (B,T//4,num_hiddens)."""
         mfcc = _dev_f32(mfcc, self._dev())
         B, T, _ = mfcc.shape
+        if T < 4:
+            raise RuntimeError(f"sequence too short: {T} frames (need >= 4 for one code row)")
         out = torch.empty((B, T // 2 // 2, self.num_hiddens), dtype=torch.float32, device=mfcc.device)
         _lib.check(_lib.load().ts_audioenc_forward(self.handle(), _lib.dptr(mfcc), B, T, _lib.dptr(out), _lib.stream_ptr()))
         return out
@@ -166,6 +168,8 @@ class VQVAE(NativeModule):
     def encode_nlc(self, poses, want_z=False, want_quantized=True):
         poses = _dev_f32(poses, self._dev())
         B, T, _ = poses.shape
+        if T < 4:
+            raise RuntimeError(f"sequence too short: {T} frames (need >= 4 for one code row)")
         H = T // 2 // 2
         lat = torch.empty((B, H), dtype=torch.int64, device=poses.device)
         z = torch.empty((B, H, self.embedding_dim), dtype=torch.float32, device=poses.device) if want_z else None

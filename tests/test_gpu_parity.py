@@ -408,3 +408,22 @@ def test_single_layer_pixelcnn(hip):
     ref, rl = O.pixelcnn_generate(label, np.repeat(aud.transpose(0, 2, 1)[:, :, :, None], 2, axis=3), sd, 1, 5, return_logits=True)
     np.testing.assert_allclose(logits.cpu().numpy(), rl, atol=3e-4, rtol=0)
     np.testing.assert_array_equal(codes.cpu().numpy(), ref)
+
+
+def test_error_behaviour(hip):
+    """Inputs the path cannot process fail loudly through ts_last_error (no silent fallback, no crash)."""
+    from talkshow_amd.modules import AudioEncoder, FaceGenerator, VQVAE
+    ae = AudioEncoder(64, 256, 2).cuda()
+    with pytest.raises(RuntimeError, match="too short"):
+        ae.forward_nlc(np.zeros((1, 3, 64), np.float32))                       # fewer than 4 frames: no code row at all
+    vq = VQVAE(39, 64, 128, 128, 2).cuda()
+    with pytest.raises(RuntimeError, match="too short"):
+        vq.encode_nlc(np.zeros((2, 2, 39), np.float32))
+    with pytest.raises(RuntimeError, match="size mismatch|missing"):
+        vq.load_state_dict({"encoder.project.conv.weight": torch.zeros(1)})
+    fg = FaceGenerator(n_layers=1).cuda()
+    fg.load_state_dict(synth.to_torch(synth.face_state_dict(seed=1, n_layers=1)))
+    with pytest.raises(RuntimeError, match="too short"):
+        fg.run(np.zeros((1, 300), np.float32), np.zeros((1, 4), np.float32), 1)   # below the 400-sample receptive field
+    out = fg.run(synth.wav16(1, 1, 4000), np.zeros((1, 4), np.float32), 7)
+    assert out.shape == (1, 7, 103) and torch.isfinite(out).all()
