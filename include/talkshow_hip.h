@@ -31,6 +31,7 @@ typedef struct ts_convnet ts_convnet;     /* AudioEncoder            nets/spg/vq
 typedef struct ts_vqvae ts_vqvae;         /* VQVAE                   nets/spg/vqvae_1d.py:152-208        */
 typedef struct ts_pixelcnn ts_pixelcnn;   /* GatedPixelCNN           nets/spg/gated_pixelcnn_v2.py:90-177 */
 typedef struct ts_face ts_face;           /* s2g_face.Generator      nets/spg/s2g_face.py:142-224        */
+typedef struct ts_mfcc ts_mfcc;           /* get_mfcc_ta front-end   data_utils/utils.py:148-231         */
 
 /* One entry of a reference state_dict: key name as the reference spells it (an optional "module." prefix is
  * accepted and stripped, nets/smplx_body_pixel.py:119-126), fp32 host data, shape.  int64 buffers
@@ -124,6 +125,17 @@ void ts_face_destroy(ts_face *face);
  * hidden_dev optional (B,frames,768): the wav2vec2 last_hidden_state (parity tests). */
 int ts_face_generate(ts_face *face, const float *wav_dev, int B, int N, int frames, const float *id_dev, float *out_dev,
                      float *hidden_dev, void *stream);
+
+/* ---- audio front-end on the device: get_mfcc_ta (data_utils/utils.py:148-231) = torchaudio Resample(sr_in -> sr_out)
+ * + MFCC(n_mfcc=64, n_fft=2048, n_mels=256, hop = 734 (fps 30) | 1467 (fps 15), mel_scale='htk').  torchaudio is
+ * third-party and absent from the image: its published definitions are restated; parity against it is unpinned. ---- */
+int ts_mfcc_create(ts_ctx *ctx, int sr_in, int sr_out, int fps, ts_mfcc **out);
+void ts_mfcc_destroy(ts_mfcc *m);
+/* frames for N input samples: floor(ceil(N * sr_out / sr_in) / hop) + 1 */
+int ts_mfcc_num_frames(const ts_mfcc *m, long N);
+/* wav_dev (B,N) mono fp32 at sr_in (multi-channel files: resample each channel, then average, as utils.py:150-154 —
+ * resampling is linear, so averaging first is the same signal) -> feat_dev (B,T,64), T = ts_mfcc_num_frames(m, N). */
+int ts_mfcc_forward(ts_mfcc *m, const float *wav_dev, int B, long N, float *feat_dev, void *stream);
 
 /* ---- whole wrappers --------------------------------------------------------------------------------------- */
 /* s2g_body_pixel.TrainWrapper.infer_on_audio after the MFCC front-end (smplx_body_pixel.py:272-285):

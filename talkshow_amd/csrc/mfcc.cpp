@@ -1,0 +1,180 @@
+// Device audio front-end: waveform -> (resample to 22 kHz) -> MFCC(64) as the reference computes it on the CPU with
+// torchaudio (data_utils/utils.py:148-231: Resample(sr_0, 22000) per channel, MFCC(n_mfcc=64, n_fft=2048, n_mels=256,
+// hop=734|1467, mel_scale='htk')).  torchaudio is third-party and not available in this image: the constants below
+// restate its published definitions (sinc_interp_hann kernel with lowpass_filter_width 6 / rolloff 0.99; periodic Hann;
+// HTK mel filterbank f_min 0, f_max sr/2, norm None; 10*log10(clamp 1e-10), top_db 80 per clip; orthonormal DCT-II).
+// PARITY UNPINNED against torchaudio; pinned against talkshow_amd/frontend.py (same formulae in numpy) on the GPU.
+// The STFT is a DFT-as-GEMM on conv_gemm_f32 (2048 x 2050 real matrix, [cos | -sin] interleaved): 1.26 GMAC per 10 s
+// clip, exact fp32 MFMA accumulation, no FFT library needed.
+#include <cmath>
+
+#include "host_common.h"
+
+using namespace ts;
+
+namespace ts {
+hipError_t launch_resample_polyphase(const float *x, int B, int N, const float *kern, int norig, int nnew, int width, int kw,
+                                     float *out, int Nout, hipStream_t s);
+hipError_t launch_frame_window(const float *x, int B, int N, int T, int hop, int nfft, const float *win, float *frames,
+                               hipStream_t s);
+hipError_t launch_power_spectrum(const float *spec, int lds_, int nbins, float *pw, int ldp, long rows, hipStream_t s);
+hipError_t launch_db_topdb(float *mel, int B, long per_clip, float top_db, hipStream_t s);
+}  // namespace ts
+
+struct ts_mfcc {
+    ts_ctx *ctx = nullptr;
+    int sr_in = 0, sr_out = 0, norig = 1, nnew = 1, width = 0, kw = 0;
+    int nfft = 2048, hop = 734, nmels = 256, nmfcc = 64, nbins = 1025, nbins_pad = 1056;
+    DevBuf rs_kern, window;
+    ConvLayer dft, mel, dct;
+    struct Work {
+        DevBuf x22, frames, spec, power, melb;
+    };
+    std::map<hipStream_t, std::unique_ptr<Work>> works;
+    Work &work(hipStream_t s) {
+        auto &w = works[s];
+        if (!w) w.reset(new Work());
+        return *w;
+    }
+    long resampled_len(long N) const { return (nnew * N + norig - 1) / norig; }
+};
+
+static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+extern "C" {
+
+int ts_mfcc_create(ts_ctx *ctx, int sr_in, int sr_out, int fps, ts_mfcc **out) {
+    if (!ctx || !out) return fail("ts_mfcc_create: null argument");
+    if (fps != 30 && fps != 15) return fail("ts_mfcc_create: fps must be 15 or 30 (hop 1467 / 734, utils.py:157-160)");
+    TS_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<ts_mfcc> m(new ts_mfcc());
+    m->ctx = ctx;
+    m->sr_in = sr_in;
+    m->sr_out = sr_out;
+    m->hop = fps == 30 ? 734 : 1467;
+    const double PI = 3.14159265358979323846;
+    // ---- resampling kernel (torchaudio _get_sinc_resample_kernel, sinc_interp_hann) ----
+    if (sr_in != sr_out) {
+        const int g = gcd_i(sr_in, sr_out);
+        m->norig = sr_in / g;
+        m->nnew = sr_out / g;
+        const double lpw = 6.0, rolloff = 0.99;
+        const double base = std::min(m->norig, m->nnew) * rolloff;
+        m->width = (int)std::ceil(lpw * m->norig / base);
+        m->kw = 2 * m->width + m->norig;
+        std::vector<float> k((size_t)m->nnew * m->kw);
+        for (int ph = 0; ph < m->nnew; ++ph)
+            for (int i = 0; i < m->kw; ++i) {
+                double t = ((double)(-ph) / m->nnew + (double)(i - m->width) / m->norig) * base;
+                t = std::max(-lpw, std::min(lpw, t));
+                const double win = std::pow(std::cos(t * PI / lpw / 2.0), 2.0);
+                const double tp = t * PI;
+                const double sinc = tp == 0.0 ? 1.0 : std::sin(tp) / tp;
+                k[(size_t)ph * m->kw + i] = (float)(sinc * win * (base / m->norig));
+            }
+        TS_TRY(m->rs_kern.upload(k.data(), k.size() * sizeof(float)));
+    }
+    // ---- periodic Hann window ----
+    {
+        std::vector<float> w(m->nfft);
+        for (int n = 0; n < m->nfft; ++n) w[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * n / m->nfft));
+        TS_TRY(m->window.upload(w.data(), w.size() * sizeof(float)));
+    }
+    // ---- DFT matrix rows: (2f) cos(2 pi f n / N), (2f+1) -sin(2 pi f n / N) ----
+    {
+        const int N = m->nfft, nb = m->nbins;
+        std::vector<float> w((size_t)2 * nb * N);
+        for (int f = 0; f < nb; ++f)
+            for (int n = 0; n < N; ++n) {
+                const long r = ((long)f * n) % N;          // exact argument reduction
+                const double a = 2.0 * PI * (double)r / N;
+                w[((size_t)2 * f) * N + n] = (float)std::cos(a);
+                w[((size_t)2 * f + 1) * N + n] = (float)(-std::sin(a));
+            }
+        TS_TRY(pack_linear_layer(w.data(), N, nullptr, 2 * nb, N, &m->dft));
+    }
+    // ---- HTK mel filterbank (torchaudio.functional.melscale_fbanks, norm=None), transposed to [n_mels][n_freqs] ----
+    {
+        const int nb = m->nbins, nm = m->nmels;
+        auto hz2mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
+        auto mel2hz = [](double x) { return 700.0 * (std::pow(10.0, x / 2595.0) - 1.0); };
+        const double fmax = (double)(sr_out / 2);
+        std::vector<double> fpts(nm + 2);
+        const double m0 = hz2mel(0.0), m1 = hz2mel(fmax);
+        for (int i = 0; i < nm + 2; ++i) fpts[i] = mel2hz(m0 + (m1 - m0) * i / (nm + 1));
+        std::vector<float> fb((size_t)nm * m->nbins_pad, 0.f);
+        for (int f = 0; f < nb; ++f) {
+            const double freq = (double)(sr_out / 2) * f / (nb - 1);
+            for (int j = 0; j < nm; ++j) {
+                const double down = (freq - fpts[j]) / (fpts[j + 1] - fpts[j]);
+                const double up = (fpts[j + 2] - freq) / (fpts[j + 2] - fpts[j + 1]);
+                const double v = std::max(0.0, std::min(down, up));
+                fb[(size_t)j * m->nbins_pad + f] = (float)v;
+            }
+        }
+        TS_TRY(pack_linear_layer(fb.data(), m->nbins_pad, nullptr, nm, m->nbins_pad, &m->mel));
+    }
+    // ---- orthonormal DCT-II (torchaudio.functional.create_dct), [n_mfcc][n_mels] ----
+    {
+        const int nm = m->nmels, nc = m->nmfcc;
+        std::vector<float> d((size_t)nc * nm);
+        for (int k = 0; k < nc; ++k)
+            for (int n = 0; n < nm; ++n) {
+                double v = std::cos(PI / nm * (n + 0.5) * k);
+                if (k == 0) v *= 1.0 / std::sqrt(2.0);
+                d[(size_t)k * nm + n] = (float)(v * std::sqrt(2.0 / nm));
+            }
+        TS_TRY(pack_linear_layer(d.data(), nm, nullptr, nc, nm, &m->dct));
+    }
+    *out = m.release();
+    return 0;
+}
+void ts_mfcc_destroy(ts_mfcc *m) { delete m; }
+
+// number of MFCC frames for N input samples: T = floor(N_resampled / hop) + 1 (center=True)
+int ts_mfcc_num_frames(const ts_mfcc *m, long N) { return m ? (int)(m->resampled_len(N) / m->hop) + 1 : -1; }
+
+// wav_dev (B,N) mono fp32 at sr_in -> feat_dev (B,T,64), T = ts_mfcc_num_frames(m, N)
+int ts_mfcc_forward(ts_mfcc *m, const float *wav, int B, long N, float *feat, void *stream) {
+    if (!m || !wav || !feat) return fail("ts_mfcc_forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    ts_ctx *ctx = m->ctx;
+    const long N22 = m->resampled_len(N);
+    if (N22 <= m->nfft / 2) return fail("ts_mfcc_forward: clip shorter than half an FFT window (reflect padding undefined)");
+    const int T = (int)(N22 / m->hop) + 1;
+    const long M = (long)B * T;
+    ts_mfcc::Work &w = m->work(s);
+    const size_t F = sizeof(float);
+    const float *x22 = wav;
+    {
+        MiscScope ms(ctx, s);
+        if (m->sr_in != m->sr_out) {
+            TS_TRY(w.x22.ensure((size_t)B * N22 * F));
+            TS_HIP(launch_resample_polyphase(wav, B, (int)N, m->rs_kern.f(), m->norig, m->nnew, m->width, m->kw, w.x22.f(), (int)N22, s));
+            x22 = w.x22.f();
+        }
+        TS_TRY(w.frames.ensure((size_t)M * m->nfft * F));
+        TS_HIP(launch_frame_window(x22, B, (int)N22, T, m->hop, m->nfft, m->window.f(), w.frames.f(), s));
+    }
+    TS_TRY(w.spec.ensure((size_t)M * 2 * m->nbins * F));
+    TS_TRY(w.power.ensure((size_t)M * m->nbins_pad * F));
+    TS_TRY(w.melb.ensure((size_t)M * m->nmels * F));
+    ConvParams p;
+    conv_layer_params(m->dft, w.frames.f(), m->nfft, 1, (int)M, nullptr, 0, w.spec.f(), 2 * m->nbins, 0, 2 * m->nbins, &p);
+    TS_TRY(run_conv(ctx, p, 0, s));
+    {
+        MiscScope ms(ctx, s);
+        TS_HIP(launch_power_spectrum(w.spec.f(), 2 * m->nbins, m->nbins, w.power.f(), m->nbins_pad, M, s));
+    }
+    conv_layer_params(m->mel, w.power.f(), m->nbins_pad, 1, (int)M, nullptr, 0, w.melb.f(), m->nmels, 0, m->nmels, &p);
+    TS_TRY(run_conv(ctx, p, 0, s));
+    {
+        MiscScope ms(ctx, s);
+        TS_HIP(launch_db_topdb(w.melb.f(), B, (long)T * m->nmels, 80.0f, s));
+    }
+    conv_layer_params(m->dct, w.melb.f(), m->nmels, 1, (int)M, nullptr, 0, feat, m->nmfcc, 0, m->nmfcc, &p);
+    TS_TRY(run_conv(ctx, p, 0, s));
+    return 0;
+}
+
+}  // extern "C"

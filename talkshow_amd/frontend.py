@@ -142,13 +142,34 @@ def _load_mono_resampled(aud_fn, sr):
     return audio[0]
 
 
-def get_mfcc_ta(aud_fn, sr=22000, fps=30, smlpx=True, type='mfcc', am=None, am_sr=None, encoder_choice='mfcc'):
-    """`get_mfcc_ta` (`utils.py:148-231`), body branch: -> (T, 64) float32 features."""
+_device_mfcc = {}
+
+
+def _mfcc_on_device(wave_mono, sr_in, sr, fps):
+    """MI355X path of the front-end (ts_mfcc_*): resample + MFCC on the GPU when one is present."""
+    from .modules import MFCC
+    key = (int(sr_in), int(sr), int(fps), torch.cuda.current_device())
+    if key not in _device_mfcc:
+        _device_mfcc[key] = MFCC(sr_in, sr, fps)
+    return _device_mfcc[key](wave_mono)[0].cpu().numpy()
+
+
+def get_mfcc_ta(aud_fn, sr=22000, fps=30, smlpx=True, type='mfcc', am=None, am_sr=None, encoder_choice='mfcc', host=None):
+    """`get_mfcc_ta` (`utils.py:148-231`), body branch: -> (T, 64) float32 features.
+
+    wav files: resample + MFCC run on the GPU (ts_mfcc_forward) when a HIP device is present, else on the host in numpy
+    (`host=True` forces the numpy path, which is also the checker of the device path in tests/)."""
     feat = _features_from_any(aud_fn)
     if feat is None:
         if type != 'mfcc':
             raise NotImplementedError("only type='mfcc' is on the inference path")
-        feat = mfcc(_load_mono_resampled(aud_fn, sr), sr, hop_length=_hop(fps)).T
+        use_host = host if host is not None else not torch.cuda.is_available()
+        if use_host:
+            feat = mfcc(_load_mono_resampled(aud_fn, sr), sr, hop_length=_hop(fps)).T
+        else:
+            audio, sr_0 = load_wav(aud_fn)
+            _hop(fps)
+            feat = _mfcc_on_device(audio.mean(axis=0, dtype=F32), sr_0, sr, fps)
     feat = np.asarray(feat, dtype=np.float32)
     if feat.ndim != 2 or feat.shape[1] != 64:
         raise ValueError(f"MFCC features must have shape (T, 64), got {feat.shape}")

@@ -343,3 +343,32 @@ class FaceGenerator(NativeModule):
         wav = _dev_f32(in_spec, self._dev())
         wav = wav.reshape(wav.shape[0], -1)
         return self.run(wav, id, time_steps), None
+
+
+class MFCC:
+    """Device front-end: `get_mfcc_ta` = torchaudio Resample(sr_in -> sr_out) + MFCC(64) (`data_utils/utils.py:148-231`)."""
+
+    def __init__(self, sr_in, sr_out=22000, fps=30, device=None):
+        self.sr_in, self.sr_out, self.fps = int(sr_in), int(sr_out), int(fps)
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        self._dev = torch.device("cuda", idx if idx is not None else torch.cuda.current_device())
+        h = C.c_void_p()
+        _lib.check(_lib.load().ts_mfcc_create(_lib.context(self._dev.index), self.sr_in, self.sr_out, self.fps, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            _lib.load().ts_mfcc_destroy(self._h)
+        except Exception:
+            pass
+
+    def __call__(self, wav):
+        """wav (B,N) or (N,) mono samples at sr_in -> (B,T,64) device tensor."""
+        wav = _dev_f32(wav, self._dev)
+        if wav.ndim == 1:
+            wav = wav[None]
+        B, N = wav.shape
+        T = _lib.load().ts_mfcc_num_frames(self._h, N)
+        out = torch.empty((B, T, 64), dtype=torch.float32, device=self._dev)
+        _lib.check(_lib.load().ts_mfcc_forward(self._h, _lib.dptr(wav), B, N, _lib.dptr(out), _lib.stream_ptr()))
+        return out

@@ -427,3 +427,31 @@ def test_error_behaviour(hip):
         fg.run(np.zeros((1, 300), np.float32), np.zeros((1, 4), np.float32), 1)   # below the 400-sample receptive field
     out = fg.run(synth.wav16(1, 1, 4000), np.zeros((1, 4), np.float32), 7)
     assert out.shape == (1, 7, 103) and torch.isfinite(out).all()
+
+
+def test_device_mfcc_vs_host_restatement(hip, tmp_path):
+    """ts_mfcc_* (polyphase resample + DFT-as-GEMM + mel + dB/top_db + DCT on the GPU) against the numpy restatement of
+    the same torchaudio definitions (talkshow_amd/frontend.py; both unpinned against torchaudio itself)."""
+    from scipy.io import wavfile
+    from talkshow_amd import frontend as fe
+    from talkshow_amd.modules import MFCC
+    rng = np.random.default_rng(3)
+    t = np.arange(160000) / 16000.0
+    wav = (0.2 * np.sin(2 * np.pi * 220 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.05 * rng.standard_normal(t.size)).astype(np.float32)
+    wav2 = (0.1 * rng.standard_normal(t.size)).astype(np.float32)
+    dev = MFCC(16000, 22000, 30)(np.stack([wav, wav2])).cpu().numpy()
+    for i, w_ in enumerate((wav, wav2)):
+        x22 = fe.resample_sinc_hann(w_[None], 16000, 22000)[0]
+        ref = fe.mfcc(x22, 22000, hop_length=734).T
+        assert dev[i].shape == ref.shape == (300 if len(x22) // 734 + 1 == 300 else len(x22) // 734 + 1, 64)
+        # coefficients are O(10..1000); fp32 DFT-as-GEMM vs pocketfft differ by summation order only
+        np.testing.assert_allclose(dev[i], ref, atol=0.05, rtol=2e-4)
+    # no resampling branch + the wav-file entry point used by infer_on_audio
+    x = (0.3 * rng.standard_normal(22000 * 2)).astype(np.float32)
+    np.testing.assert_allclose(MFCC(22000, 22000, 30)(x)[0].cpu().numpy(), fe.mfcc(x, 22000).T, atol=0.05, rtol=2e-4)
+    p = str(tmp_path / "a.wav")
+    wavfile.write(p, 16000, np.stack([wav, wav2], 1))                       # stereo float wav
+    a = fe.get_mfcc_ta(p, sr=22000, fps=30)                                    # device path
+    b = fe.get_mfcc_ta(p, sr=22000, fps=30, host=True)                         # numpy path
+    assert a.shape == b.shape and a.shape[1] == 64
+    np.testing.assert_allclose(a, b, atol=0.05, rtol=2e-4)
