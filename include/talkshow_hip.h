@@ -52,6 +52,12 @@ const char *ts_version(void);
 /* Non-blocking HIP streams for keeping several independent batches in flight on one GPU (the library keeps one
  * scratch arena per stream; weights are shared).  *out is a hipStream_t. */
 int ts_stream_create(ts_ctx *ctx, void **out);
+/* Like ts_stream_create, but kernels of this stream only run on compute units [cu_first, cu_first+cu_count) of the
+ * device's CU-mask index space (hipExtStreamCreateWithCUMask).  No reference counterpart. */
+int ts_stream_create_cus(ts_ctx *ctx, int cu_first, int cu_count, void **out_stream);
+/* Tuning aid: with TS_SKINNY_TRACE=1 the chain kernel stamps the device wall clock (100 MHz) at five points; this reads
+ * (and resets) the records, 6 uint64 each.  Returns the number of records or -1. */
+int ts_debug_skinny_trace(unsigned long long *out, int max_records);
 int ts_stream_destroy(ts_ctx *ctx, void *stream);
 
 /* ---- AudioEncoder(in_dim=64, num_hiddens, num_residual_layers, ·)  — vqvae_1d.py:11-34 ------------------ */

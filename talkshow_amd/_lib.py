@@ -29,6 +29,8 @@ SIGNATURES = {
     "ts_last_error": (C.c_char_p, []),
     "ts_version": (C.c_char_p, []),
     "ts_stream_create": (_i, [_vp, C.POINTER(_vp)]),
+    "ts_stream_create_cus": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "ts_debug_skinny_trace": (_i, [C.POINTER(C.c_uint64), _i]),
     "ts_stream_destroy": (_i, [_vp, _vp]),
     "ts_audioenc_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, C.POINTER(_vp)]),
     "ts_convnet_destroy": (None, [_vp]),
@@ -129,13 +131,18 @@ def pack_state_dict(sd):
     return arr, len(items), keep
 
 
-def create_streams(n, device_index=None):
-    """n library-created HIP streams wrapped as torch ExternalStreams (created back to back -> distinct HW queues)."""
+def create_streams(n, device_index=None, cus=None):
+    """n library-created HIP streams wrapped as torch ExternalStreams (created back to back -> distinct HW queues).
+
+    cus=(first, count) restricts their kernels to that range of compute units (ts_stream_create_cus)."""
     ctx = context(device_index)
     out = []
     for _ in range(n):
         h = _vp()
-        check(load().ts_stream_create(ctx, C.byref(h)))
+        if cus is None:
+            check(load().ts_stream_create(ctx, C.byref(h)))
+        else:
+            check(load().ts_stream_create_cus(ctx, int(cus[0]), int(cus[1]), C.byref(h)))
         out.append(torch.cuda.ExternalStream(h.value, device=torch.device("cuda", device_index if device_index is not None
                                                                               else torch.cuda.current_device())))
     return out

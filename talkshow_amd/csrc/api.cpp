@@ -1,4 +1,5 @@
 // Whole-wrapper entry points and the single-operator entry points used by the kernel-level parity tests.
+#include <vector>
 #include "host_common.h"
 
 using namespace ts;
@@ -28,6 +29,28 @@ int ts_stream_create(ts_ctx *ctx, void **out) {
     TS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *out = s;
     return 0;
+}
+// A stream whose kernels only run on compute units [cu_first, cu_first + cu_count) of the device's CU-mask index space
+// (consecutive mask bits are spread round-robin over the 8 XCDs).  Used to keep the latency-bound PixelCNN chain and the
+// MFMA-bound conv stacks of different batches off each other's CUs.
+int ts_stream_create_cus(ts_ctx *ctx, int cu_first, int cu_count, void **out) {
+    if (!ctx || !out) return fail("ts_stream_create_cus: null argument");
+    TS_HIP(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    TS_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    const int ncu = prop.multiProcessorCount;
+    if (cu_first < 0 || cu_count < 1 || cu_first + cu_count > ncu) return fail("ts_stream_create_cus: CU range outside the device");
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int i = cu_first; i < cu_first + cu_count; ++i) mask[i / 32] |= 1u << (i % 32);
+    hipStream_t s = nullptr;
+    TS_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    *out = s;
+    return 0;
+}
+// tuning aid (TS_SKINNY_TRACE=1): in-kernel wall-clock stamps of the PixelCNN chain kernel, 6 u64 per record
+int ts_debug_skinny_trace(unsigned long long *out, int max_records) {
+    if (!out) return -1;
+    return ts::skinny_trace_read(out, max_records);
 }
 int ts_stream_destroy(ts_ctx *ctx, void *stream) {
     if (!ctx) return fail("ts_stream_destroy: null ctx");

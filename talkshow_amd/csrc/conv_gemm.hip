@@ -20,17 +20,17 @@
 //   * convolution taps / stride / transposed-conv phases are "segments": (row shift, channel range) pairs, so only
 //     valid taps are multiplied (no zero-insertion for ConvTranspose, no wasted taps for stride 2).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace ts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;   // 36 floats = 144 B row pitch
-
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 32>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+    constexpr int LDS_LD = BK + 4;   // 36 (68) floats: conflict-free row pitch for ds_read_b128
+    constexpr int KC = BK / 32;      // 32-float column blocks per chunk
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int PA = BM / 32, PB = BN / 32;   // 32-row load passes per operand
@@ -75,29 +75,37 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
     const float *wbase = gw + (long)(n0 + lrow) * ldw + lc4;
 
-    f32x4 ra[PA], rb[PB];
+    f32x4 ra[PA][KC], rb[PB][KC];
     auto load_chunk = [&](int s, int tap, int cc, int kofs) {
         const int d = g.seg[s].d + tap;
         const int coff = g.seg[s].c0 + cc * BK + lc4;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             int it = a_t[i] + d;
-            if (a_rowbase[i] >= 0 && it >= 0 && it < p.Lin)
-                ra[i] = *reinterpret_cast<const f32x4 *>(gx + (a_rowbase[i] + it) * p.ldx + coff);
-            else
-                ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = a_rowbase[i] >= 0 && it >= 0 && it < p.Lin;
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+                ra[i][c] = ok ? *reinterpret_cast<const f32x4 *>(gx + (a_rowbase[i] + it) * p.ldx + coff + c * 32)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            if (n0 + i * 32 + lrow < w_rows) rb[i] = *reinterpret_cast<const f32x4 *>(wbase + (long)i * 32 * ldw + kofs);
-            else rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = n0 + i * 32 + lrow < w_rows;
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+                rb[i][c] = ok ? *reinterpret_cast<const f32x4 *>(wbase + (long)i * 32 * ldw + kofs + c * 32)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4 *>(&As[buf][i * 32 + lrow][lc4]) = ra[i];
+        for (int i = 0; i < PA; ++i)
 #pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4 *>(&Bs[buf][i * 32 + lrow][lc4]) = rb[i];
+            for (int c = 0; c < KC; ++c) *reinterpret_cast<f32x4 *>(&As[buf][i * 32 + lrow][lc4 + c * 32]) = ra[i][c];
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) *reinterpret_cast<f32x4 *>(&Bs[buf][i * 32 + lrow][lc4 + c * 32]) = rb[i][c];
     };
 
     f32x16 acc[TM][TN];
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             load_chunk(s, tap, cc, kofs);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < BK / 8; ++q) {
             f32x4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -185,11 +193,13 @@ static int pick_tile(const ConvParams &p) {
     // the 128x128 tile (half the L2->LDS traffic per MAC).
     struct Cand { int id, bm, bn; double eff; };
     static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.89}, {3, 128, 64, 0.90}, {4, 64, 128, 0.93}};
+    static const int tp = getenv("TS_CONV_TP") ? atoi(getenv("TS_CONV_TP")) : 0;
     int best = 2;
     double best_cost = 1e300;
     for (const Cand &c : cands) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * p.ngroups;
-        const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
+        const double waves = tp == 1 ? (double)tiles / 256.0 : tp == 2 ? 0.5 * ((double)tiles / 256.0 + (tiles + 255) / 256) : (double)((tiles + 255) / 256);
+        const double cost = waves * c.bm * c.bn / c.eff;
         if (cost < best_cost) { best_cost = cost; best = c.id; }
     }
     return best;
@@ -204,6 +214,9 @@ hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream) {
         case 2: hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32>), grid(64, 64), block, 0, stream, p); break;
         case 3: hipLaunchKernelGGL((conv_gemm_kernel<128, 64, 64, 32>), grid(128, 64), block, 0, stream, p); break;
         case 4: hipLaunchKernelGGL((conv_gemm_kernel<64, 128, 32, 64>), grid(64, 128), block, 0, stream, p); break;
+        case 5:   // 64x64 with 64-deep chunks (all segment lengths must be multiples of 64)
+            hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32, 64>), grid(64, 64), block, 0, stream, p);
+            break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -107,6 +107,11 @@ struct SkinnyBatch {
 
 hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream);
 hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t stream);
+// allocates the per-device zero buffer the fast skinny kernel substitutes for absent operands (call once per device,
+// outside stream capture; without it the generic kernels are used)
+hipError_t skinny_init(int device);
+// TS_SKINNY_TRACE=1 instrumentation: records of 6 u64 {t_entry, t_desc, t_mfma_done, t_reduced, t_end, cnt<<32|workgroups}
+int skinny_trace_read(unsigned long long *out, int max_records);
 
 // ------------------------------------------------------------------------------------------------
 // VQ / sampling / glue kernels

@@ -595,6 +595,7 @@ int ts_ctx_create(int device, ts_ctx **out) {
     c->device = device;
     const int m1 = -1;
     TS_TRY(c->neg1.upload(&m1, sizeof(int)));
+    TS_HIP(ts::skinny_init(device));
     *out = c.release();
     return 0;
 }

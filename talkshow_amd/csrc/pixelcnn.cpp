@@ -65,7 +65,8 @@ struct ts_pixelcnn {
         // every pointer inside the captured kernels is one of the buffers above or the staging buffers below, so a graph
         // is valid for any caller pointers; key = (B, H, H0, mode)
         DevBuf codes_int, unif_int, dyn;
-        uint64_t dyn_host[2] = {0, 0};   // source of the async H2D copy: must outlive the call
+        uint64_t dyn_host[16][2] = {};   // ring of sources for the async H2D copy of {seed, clip0}: must outlive the call
+        unsigned dyn_slot = 0;
         hipStream_t cap_stream = nullptr;
         std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
         std::map<std::tuple<int, int, int, int>, std::pair<long, double>> graph_stats;   // skinny launches, flops
@@ -749,10 +750,11 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
 
     if (mode == TS_SAMPLE_UNIFORMS)
         TS_HIP(hipMemcpyAsync(w->unif_int.p, uniforms, (size_t)B * H * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    // the copy is made synchronous w.r.t. the host buffer: one generate per Work at a time (single host thread)
-    w->dyn_host[0] = seed;
-    w->dyn_host[1] = (uint64_t)clip0;
-    TS_HIP(hipMemcpyAsync(w->dyn.p, w->dyn_host, sizeof(w->dyn_host), hipMemcpyHostToDevice, s));
+    // the host source of the async copy must stay intact until the copy has executed: a ring of 16 slots per Work
+    uint64_t *dh = w->dyn_host[w->dyn_slot++ & 15];
+    dh[0] = seed;
+    dh[1] = (uint64_t)clip0;
+    TS_HIP(hipMemcpyAsync(w->dyn.p, dh, 2 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     const auto key = std::make_tuple(B, H, H0, mode);
     auto it = w->graphs.find(key);
     if (it == w->graphs.end()) {

@@ -11,6 +11,8 @@
 // term), the class conditioning and the tanh*sigmoid gate: the tile's columns are 16 "tanh" channels followed by
 // their 16 "sigmoid" partners, so the gate is one cross-lane exchange (lane ^ 16).
 #include <cstdlib>
+#include <cstring>
+#include <cstdint>
 
 #include "kernels.h"
 
@@ -294,6 +296,318 @@ __global__ __launch_bounds__(W * 64) void skinny16_kernel(const SkinnyBatch batc
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path of the 16-column kernel.  A chain stage lasts a few microseconds, so what matters is the number of DEPENDENT
+// memory round trips between wave start and the first MFMA.  The generic kernels above read their problem description
+// field by field from the kernarg segment (a dozen dependent scalar loads, cold after every kernel boundary) and fetch
+// the optional epilogue operands one after the other.  Here
+//   * the problem is a 64-dword descriptor: every wave fetches it with ONE vector load (lane i holds word i) and pulls
+//     fields out with v_readlane — one round trip, no LDS, no scalar-cache misses;
+//   * optional operands never branch: the host points absent ones at a zero buffer (stride 0), rows beyond M are
+//     clamped (their results are never stored), so all operand loads of the wave — weights, activations, bias and
+//     additive terms — are issued back to back and overlap: a second (and last) round trip;
+//   * a wave's share of K is CNT = K / (16 W) <= 4 q-steps inside one segment (host-checked), straight-line code.
+// Partition of K over waves and the LDS summation order are those of skinny16_kernel: results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------
+enum {   // descriptor word indices
+    SD_M = 0, SD_N, SD_CNT, SD_FLAGS, SD_GATED, SD_GX, SD_GY, SD_NSEG,
+    SD_W = 8, SD_LDW = 10, SD_BIAS = 11,
+    SD_ADD1 = 13, SD_ADD1_STRIDE = 15, SD_ADD1_SHIFT = 16,
+    SD_ADD2 = 17, SD_ADD2_STRIDE = 19, SD_ADD2_SHIFT = 20,
+    SD_ADD3 = 21, SD_ADD3_STRIDE = 23,
+    SD_CLS = 24, SD_CLS_LD = 26,
+    SD_OUT = 27, SD_OUT_STRIDE = 29, SD_PRE = 30, SD_PRE_STRIDE = 32,
+    SD_SEG = 33,   // per segment: base(2) gidx(2) row_stride gidx_stride row_shift len16
+    SD_SEG_WORDS = 8,
+    SD_ZERO = 57,
+};
+enum { SDF_GATE = 1, SDF_RELU = 2, SDF_PRE = 4 };
+struct SkinnyDesc { uint32_t w[64]; };
+struct SkinnyDescBatch {
+    int start[8];   // first workgroup of problem i (1-D grid over live tiles only); INT_MAX for unused problems
+    SkinnyDesc d[SKINNY_MAX_PROBLEMS];
+};
+
+// descriptor pointers are rebuilt from integers: tag them as global (address space 1) so the loads are global_load, not flat
+typedef __attribute__((address_space(1))) const float gcf;
+typedef __attribute__((address_space(1))) float gf;
+typedef __attribute__((address_space(1))) const int gci;
+typedef __attribute__((address_space(1))) const f32x4 gcf4;
+
+template <int CNT>
+__device__ __forceinline__ void skinny16_load(gcf *ap0, gcf *ap1, gcf *bp, f32x4 (&a0)[8], f32x4 (&a1)[8], f32x4 (&b)[8]) {
+#pragma unroll
+    for (int u = 0; u < CNT; ++u) {
+        b[u] = *reinterpret_cast<gcf4 *>(bp + u * 16);
+        a0[u] = *reinterpret_cast<gcf4 *>(ap0 + u * 16);
+        a1[u] = *reinterpret_cast<gcf4 *>(ap1 + u * 16);
+    }
+}
+template <int CNT>
+__device__ __forceinline__ void skinny16_mfma(const f32x4 (&a0)[8], const f32x4 (&a1)[8], const f32x4 (&b)[8], f32x4 &acc0, f32x4 &acc1) {
+#pragma unroll
+    for (int u = 0; u < CNT; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u][e], b[u][e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][e], b[u][e], acc1, 0, 0, 0);
+        }
+}
+
+// TRACE instrumentation (tools/skinny_trace.py): workgroup (0,0,0), wave 0 stamps the 100 MHz wall clock at five points
+constexpr unsigned TRACE_SLOTS = 1u << 20;
+__device__ unsigned long long *g_trace;   // [TRACE_SLOTS][6], allocated by skinny_init when TS_SKINNY_TRACE is set
+__device__ unsigned g_trace_n;
+
+template <int W, bool TRACE = false>
+__global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescBatch batch) {
+    __shared__ float red[W][8][64];
+    unsigned long long tr[5] = {0, 0, 0, 0, 0};
+    if (TRACE) tr[0] = wall_clock64();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+
+    // the grid is 1-D over the live tiles of all problems: fetch every problem's descriptor word (independent loads, one
+    // round trip) while the scalar unit finds the problem this workgroup belongs to
+    int dws[SKINNY_MAX_PROBLEMS];
+#pragma unroll
+    for (int i = 0; i < SKINNY_MAX_PROBLEMS; ++i) dws[i] = (int)batch.d[i].w[lane];
+    const int bx = blockIdx.x;
+    int z = 0, first = 0;
+#pragma unroll
+    for (int i = 1; i < SKINNY_MAX_PROBLEMS; ++i) {
+        const int st = batch.start[i];
+        if (bx >= st) { z = i; first = st; }
+    }
+    int dw = dws[0];
+#pragma unroll
+    for (int i = 1; i < SKINNY_MAX_PROBLEMS; ++i) dw = z == i ? dws[i] : dw;
+    auto I = [&](int k) { return __builtin_amdgcn_readlane(dw, k); };
+    auto P = [&](int k) {
+        return (gcf *)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(dw, k + 1) << 32) |
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readlane(dw, k));
+    };
+    const int gx = I(SD_GX);
+    const int mt = (bx - first) / gx, tile = (bx - first) - mt * gx;
+    if (TRACE) tr[1] = wall_clock64();
+
+    const int M = I(SD_M), N = I(SD_N), flags = I(SD_FLAGS), gateD = I(SD_GATED);
+    const bool gate = flags & SDF_GATE;
+    int n;
+    if (gate) {
+        const int tiles_per_group = gateD >> 3;
+        const int group = tile / tiles_per_group, ch0 = (tile - group * tiles_per_group) << 3;
+        n = group * 2 * gateD + (li >> 3) * gateD + ch0 + (li & 7);
+    } else {
+        n = tile * 16 + li;
+    }
+    const bool n_ok = n < N;
+    const int nc = n_ok ? n : 0;
+
+    // ---- this wave's K range: CNT q-steps (16 k each) inside one segment ----
+    const int cnt = I(SD_CNT);
+    const int q0 = wave * cnt;
+    int sbase = SD_SEG, qs = 0;
+    {
+        const int nseg = I(SD_NSEG);
+        const int l0 = I(SD_SEG + 7);
+        if (nseg > 1 && q0 >= l0) {
+            sbase = SD_SEG + SD_SEG_WORDS;
+            qs = l0;
+            const int l1 = I(SD_SEG + SD_SEG_WORDS + 7);
+            if (nseg > 2 && q0 >= l0 + l1) {
+                sbase = SD_SEG + 2 * SD_SEG_WORDS;
+                qs = l0 + l1;
+            }
+        }
+    }
+    gcf *base = P(sbase);
+    gci *gidx = (gci *)P(sbase + 2);
+    const int row_stride = I(sbase + 4), row_shift = I(sbase + 6);
+    const int m0 = mt * 32 + li, m1 = m0 + 16;
+    const int m0c = m0 < M ? m0 : M - 1, m1c = m1 < M ? m1 : M - 1;   // clamped rows: computed, never stored
+    gcf *ar0, *ar1;
+    if (gidx) {   // wave-uniform: token-embedding gather (one extra round trip, first stage of column 1 only)
+        const int gstride = I(sbase + 5);
+        const int g0 = gidx[(long)m0c * gstride], g1 = gidx[(long)m1c * gstride];
+        gcf *zero = P(SD_ZERO);
+        ar0 = g0 >= 0 ? base + (long)g0 * row_stride : zero;
+        ar1 = g1 >= 0 ? base + (long)g1 * row_stride : zero;
+    } else {
+        ar0 = base + (long)(m0c >> row_shift) * row_stride;
+        ar1 = base + (long)(m1c >> row_shift) * row_stride;
+    }
+    const int koff = (q0 - qs) * 16 + lg * 4;
+    gcf *bp = P(SD_W) + (long)nc * I(SD_LDW) + q0 * 16 + lg * 4;
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int RPW = 8 / W;
+    float e_add[RPW], e_cls[RPW];
+    auto epilogue_operands = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave * RPW + rr;
+            const int row = mt * 32 + (r >> 2) * 16 + lg * 4 + (r & 3);
+            const int rowc = row < M ? row : 0;
+            const float t0 = P(SD_BIAS)[nc];
+            const float t1 = P(SD_ADD1)[(long)(rowc >> I(SD_ADD1_SHIFT)) * I(SD_ADD1_STRIDE) + nc];
+            const float t2 = P(SD_ADD2)[(long)(rowc >> I(SD_ADD2_SHIFT)) * I(SD_ADD2_STRIDE) + nc];
+            const float t3 = P(SD_ADD3)[(long)rowc * I(SD_ADD3_STRIDE) + nc];
+            const int cls_ld = I(SD_CLS_LD);
+            e_cls[rr] = P(SD_CLS)[(long)rowc * cls_ld + (nc % cls_ld)];
+            e_add[rr] = ((t0 + t1) + t2) + t3;
+        }
+    };
+    // phase 1: every load of this wave — K operands first (they are waited for first), then the epilogue operands
+    f32x4 a0[8], a1[8], b[8];
+    if (cnt == 8) skinny16_load<8>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
+    else if (cnt == 4) skinny16_load<4>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
+    else if (cnt == 2) skinny16_load<2>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
+    else if (cnt == 1) skinny16_load<1>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
+    else skinny16_load<3>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
+    epilogue_operands();
+    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from sinking loads between the MFMAs
+    // phase 2
+    if (cnt == 8) skinny16_mfma<8>(a0, a1, b, acc0, acc1);
+    else if (cnt == 4) skinny16_mfma<4>(a0, a1, b, acc0, acc1);
+    else if (cnt == 2) skinny16_mfma<2>(a0, a1, b, acc0, acc1);
+    else if (cnt == 1) skinny16_mfma<1>(a0, a1, b, acc0, acc1);
+    else skinny16_mfma<3>(a0, a1, b, acc0, acc1);
+    if (TRACE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[2] = wall_clock64();
+    }
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[wave][r][lane] = acc0[r];
+        red[wave][4 + r][lane] = acc1[r];
+    }
+    __syncthreads();
+    if (TRACE) tr[3] = wall_clock64();
+
+    gf *out = (gf *)P(SD_OUT);
+    const int out_stride = I(SD_OUT_STRIDE);
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        float v = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < W; ++w) v += red[w][r][lane];
+        const int row = mt * 32 + (r >> 2) * 16 + lg * 4 + (r & 3);
+        const bool ok = n_ok && row < M;
+        v += e_add[rr];
+        if (gate) {
+            if ((flags & SDF_PRE) && ok) ((gf *)P(SD_PRE))[(long)row * I(SD_PRE_STRIDE) + n] = v;
+            v += e_cls[rr];
+            const float partner = __shfl_xor(v, 8);
+            if ((li & 8) == 0 && ok) {
+                const float g = tanhf(v) * (1.0f / (1.0f + expf(-partner)));
+                const int tiles_per_group = gateD >> 3;
+                const int group = tile / tiles_per_group, ch0 = (tile - group * tiles_per_group) << 3;
+                out[(long)row * out_stride + group * gateD + ch0 + (li & 7)] = g;
+            }
+        } else {
+            if (flags & SDF_RELU) v = v > 0.f ? v : 0.f;
+            if (ok) out[(long)row * out_stride + n] = v;
+        }
+    }
+    if (TRACE && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[4] = wall_clock64();
+        const unsigned slot = atomicAdd(&g_trace_n, 1u);
+        if (slot < TRACE_SLOTS) {
+            for (int k = 0; k < 5; ++k) g_trace[(size_t)slot * 6 + k] = tr[k];
+            g_trace[(size_t)slot * 6 + 5] = ((unsigned long long)z << 48) | ((unsigned long long)tile << 32) |
+                                            ((unsigned long long)I(SD_CNT) << 24) | (unsigned)(gridDim.x * gridDim.y * gridDim.z);
+        }
+    }
+}
+
+// ---- host side of the fast path ----
+constexpr size_t SKINNY_ZERO_FLOATS = 1 << 16;
+static float *g_zero[16] = {};
+hipError_t skinny_init(int device) {   // called from ts_ctx_create (never during stream capture)
+    if (device < 0 || device >= 16) return hipErrorInvalidDevice;
+    if (g_zero[device]) return hipSuccess;
+    float *z = nullptr;
+    hipError_t e = hipMalloc(&z, SKINNY_ZERO_FLOATS * sizeof(float));
+    if (e != hipSuccess) return e;
+    e = hipMemset(z, 0, SKINNY_ZERO_FLOATS * sizeof(float));
+    if (e != hipSuccess) return e;
+    g_zero[device] = z;
+    if (getenv("TS_SKINNY_TRACE") && atoi(getenv("TS_SKINNY_TRACE"))) {
+        unsigned long long *t = nullptr;
+        e = hipMalloc(&t, (size_t)TRACE_SLOTS * 6 * sizeof(unsigned long long));
+        if (e != hipSuccess) return e;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &t, sizeof(t));
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static inline void put_ptr(SkinnyDesc &d, int k, const void *p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    d.w[k] = (uint32_t)v;
+    d.w[k + 1] = (uint32_t)(v >> 32);
+}
+static inline bool fits_i32(long v) { return v >= 0 && v < (1l << 31); }
+
+// false if the problem does not meet the fast kernel's shape constraints
+static bool skinny_pack_desc(const SkinnyParams &p, int W, const float *zero, SkinnyDesc &d) {
+    if (p.Ktot % (16 * W) != 0 || p.nseg < 1) return false;
+    const int cnt = p.Ktot / (16 * W);
+    if (cnt < 1 || (cnt > 4 && cnt != 8)) return false;
+    if ((size_t)p.N > SKINNY_ZERO_FLOATS || (size_t)p.Ktot > SKINNY_ZERO_FLOATS || p.M < 1 || p.M > 4096) return false;
+    if (!fits_i32(p.ldw) || !fits_i32(p.add1_stride) || !fits_i32(p.add2_stride) || !fits_i32(p.add3_stride) ||
+        !fits_i32(p.out_stride) || !fits_i32(p.pre_stride))
+        return false;
+    std::memset(&d, 0, sizeof(d));
+    d.w[SD_M] = p.M;
+    d.w[SD_N] = p.N;
+    d.w[SD_CNT] = cnt;
+    d.w[SD_FLAGS] = (p.epi == EPI_GATE ? SDF_GATE : 0) | (p.relu ? SDF_RELU : 0) | (p.pre ? SDF_PRE : 0);
+    d.w[SD_GATED] = p.gateD;
+    d.w[SD_GX] = p.grid_x;
+    d.w[SD_GY] = p.grid_y;
+    d.w[SD_NSEG] = p.nseg;
+    put_ptr(d, SD_W, p.W);
+    d.w[SD_LDW] = (uint32_t)p.ldw;
+    put_ptr(d, SD_BIAS, p.bias ? p.bias : zero);
+    put_ptr(d, SD_ADD1, p.add1 ? p.add1 : zero);
+    d.w[SD_ADD1_STRIDE] = p.add1 ? (uint32_t)p.add1_stride : 0;
+    d.w[SD_ADD1_SHIFT] = p.add1 ? p.add1_shift : 0;
+    put_ptr(d, SD_ADD2, p.add2 ? p.add2 : zero);
+    d.w[SD_ADD2_STRIDE] = p.add2 ? (uint32_t)p.add2_stride : 0;
+    d.w[SD_ADD2_SHIFT] = p.add2 ? p.add2_shift : 0;
+    put_ptr(d, SD_ADD3, p.add3 ? p.add3 : zero);
+    d.w[SD_ADD3_STRIDE] = p.add3 ? (uint32_t)p.add3_stride : 0;
+    const bool cls = p.epi == EPI_GATE && p.clsrow;
+    put_ptr(d, SD_CLS, cls ? p.clsrow : zero);
+    d.w[SD_CLS_LD] = cls ? p.cls_ld : 1;
+    if (cls && p.cls_ld < 1) return false;
+    put_ptr(d, SD_OUT, p.out);
+    d.w[SD_OUT_STRIDE] = (uint32_t)p.out_stride;
+    put_ptr(d, SD_PRE, p.pre);
+    d.w[SD_PRE_STRIDE] = (uint32_t)p.pre_stride;
+    put_ptr(d, SD_ZERO, zero);
+    for (int s = 0; s < p.nseg; ++s) {
+        const SkinnySeg &sg = p.seg[s];
+        if (sg.len % (16 * cnt) != 0 || !fits_i32(sg.row_stride) || !fits_i32(sg.gidx_stride)) return false;
+        const int k = SD_SEG + s * SD_SEG_WORDS;
+        const bool zero_rows = !sg.gidx && !sg.base;   // null dense segment = rows of zeros
+        put_ptr(d, k, zero_rows ? zero : sg.base);
+        put_ptr(d, k + 2, sg.gidx);
+        d.w[k + 4] = zero_rows ? 0 : (uint32_t)sg.row_stride;
+        d.w[k + 5] = (uint32_t)sg.gidx_stride;
+        d.w[k + 6] = zero_rows ? 0 : sg.row_shift;
+        d.w[k + 7] = sg.len / 16;
+    }
+    return true;
+}
+
 static int skinny_grid(SkinnyParams &p, int ncol) {
     if (p.Ktot % (ncol == 16 ? 16 : 8) != 0 || p.M <= 0) return -1;
     for (int s = 0; s < p.nseg; ++s)
@@ -332,8 +646,35 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
     // fatter workgroup.  TS_SKINNY_MAXW caps it (tuning).
     static const int maxw = [] { const char *e = getenv("TS_SKINNY_MAXW"); return e ? atoi(e) : 16; }();
     if (ncol == 16) {   // Q counts 8-k steps: K = 8 Q; the 16-column kernel keeps 8 accumulators -> at most 8 waves
-        const int W16 = Q >= 32 ? 8 : 4;
-        if (W16 >= 8 && maxw >= 8) hipLaunchKernelGGL(skinny16_kernel<8>, grid, dim3(512), 0, stream, b);
+        static const int w_pref = [] { const char *e = getenv("TS_SKINNY_W"); return e ? atoi(e) : 8; }();
+        const int W16 = (Q >= 32 && maxw >= 8 && w_pref >= 8) ? 8 : 4;
+        static const int variant = [] { const char *e = getenv("TS_SKINNY_V"); return e ? atoi(e) : 1; }();
+        int dev = 0;
+        if (variant != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_zero[dev]) {
+            SkinnyDescBatch db;
+            bool fast = true;
+            int total = 0;
+            for (int i = 0; i < 8; ++i) db.start[i] = 0x7fffffff;
+            for (int i = 0; i < n && fast; ++i) {
+                fast = skinny_pack_desc(b.p[i], W16, g_zero[dev], db.d[i]);
+                db.start[i] = total;
+                total += b.p[i].grid_x * b.p[i].grid_y;
+            }
+            for (int i = n; i < SKINNY_MAX_PROBLEMS; ++i) std::memset(&db.d[i], 0, sizeof(SkinnyDesc));
+            if (fast) {
+                const dim3 grid(total);
+                static const int trace = [] { const char *e = getenv("TS_SKINNY_TRACE"); return e ? atoi(e) : 0; }();
+                if (trace) {
+                    if (W16 == 8) hipLaunchKernelGGL((skinny16_fast_kernel<8, true>), grid, dim3(512), 0, stream, db);
+                    else hipLaunchKernelGGL((skinny16_fast_kernel<4, true>), grid, dim3(256), 0, stream, db);
+                    return hipGetLastError();
+                }
+                if (W16 == 8) hipLaunchKernelGGL((skinny16_fast_kernel<8, false>), grid, dim3(512), 0, stream, db);
+                else hipLaunchKernelGGL((skinny16_fast_kernel<4, false>), grid, dim3(256), 0, stream, db);
+                return hipGetLastError();
+            }
+        }
+        if (W16 == 8) hipLaunchKernelGGL(skinny16_kernel<8>, grid, dim3(512), 0, stream, b);
         else hipLaunchKernelGGL(skinny16_kernel<4>, grid, dim3(256), 0, stream, b);
         return hipGetLastError();
     }
@@ -343,6 +684,20 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
     else if (W >= 8) hipLaunchKernelGGL(skinny_gemm_kernel<8>, grid, dim3(512), 0, stream, b);
     else hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, dim3(256), 0, stream, b);
     return hipGetLastError();
+}
+
+// copies the TRACE records to the host and resets the counter; returns the number of records
+int skinny_trace_read(unsigned long long *out, int max_records) {
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(n)) != hipSuccess) return -1;
+    if (n > TRACE_SLOTS) n = TRACE_SLOTS;
+    if ((int)n > max_records) n = max_records;
+    unsigned long long *t = nullptr;
+    if (hipMemcpyFromSymbol(&t, HIP_SYMBOL(g_trace), sizeof(t)) != hipSuccess || !t) return -1;
+    if (n && hipMemcpy(out, t, (size_t)n * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return (int)n;
 }
 
 hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream) {
