@@ -244,6 +244,9 @@ def main():
         "per_gpu_frames_per_s": frames / dt / world,
         "streams": S,
     }
+    # whole path against the fp32 MFMA roof: algorithmic work of configs[1] (64.25 MFLOP per generated frame)
+    ach = 64.25e6 * frames / dt / world / 1e12
+    out["whole_path"] = {"algorithmic_TFLOPs_per_gpu": ach, "frac_of_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS}
     # latency of ONE isolated batch (a single stream, nothing else in flight)
     lat = []
     for k in range(3):

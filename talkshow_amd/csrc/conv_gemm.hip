@@ -193,13 +193,11 @@ static int pick_tile(const ConvParams &p) {
     // the 128x128 tile (half the L2->LDS traffic per MAC).
     struct Cand { int id, bm, bn; double eff; };
     static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.89}, {3, 128, 64, 0.90}, {4, 64, 128, 0.93}};
-    static const int tp = getenv("TS_CONV_TP") ? atoi(getenv("TS_CONV_TP")) : 0;
     int best = 2;
     double best_cost = 1e300;
     for (const Cand &c : cands) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * p.ngroups;
-        const double waves = tp == 1 ? (double)tiles / 256.0 : tp == 2 ? 0.5 * ((double)tiles / 256.0 + (tiles + 255) / 256) : (double)((tiles + 255) / 256);
-        const double cost = waves * c.bm * c.bn / c.eff;
+        const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
         if (cost < best_cost) { best_cost = cost; best = c.id; }
     }
     return best;

@@ -356,13 +356,17 @@ __device__ __forceinline__ void skinny16_mfma(const f32x4 (&a0)[8], const f32x4 
 }
 
 // TRACE instrumentation (tools/skinny_trace.py): workgroup (0,0,0), wave 0 stamps the 100 MHz wall clock at five points
-constexpr unsigned TRACE_SLOTS = 1u << 20;
-__device__ unsigned long long *g_trace;   // [TRACE_SLOTS][6], allocated by skinny_init when TS_SKINNY_TRACE is set
-__device__ unsigned g_trace_n;
+constexpr unsigned TRACE_REC = 24;           // u64 per record: 5 stamps, meta, then per wave (loads back, MFMAs done)
+constexpr unsigned TRACE_WGS = 512;          // slots per launch
+constexpr unsigned TRACE_LAUNCHES = 4096;    // launches traced (launch sequence number modulo this)
+constexpr size_t TRACE_SLOTS = (size_t)TRACE_WGS * TRACE_LAUNCHES;
+__device__ unsigned long long *g_trace;   // [TRACE_SLOTS][TRACE_REC], allocated by skinny_init when TS_SKINNY_TRACE is set
+static unsigned g_trace_seq = 0;          // host: sequence number handed to the next traced launch
 
 template <int W, bool TRACE = false>
 __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescBatch batch) {
     __shared__ float red[W][8][64];
+    __shared__ unsigned long long wave_t[TRACE ? W : 1][2];
     unsigned long long tr[5] = {0, 0, 0, 0, 0};
     if (TRACE) tr[0] = wall_clock64();
     const int tid = threadIdx.x;
@@ -469,6 +473,12 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
     else skinny16_load<3>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
     epilogue_operands();
     __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from sinking loads between the MFMAs
+    unsigned long long t_loads = 0;
+    if (TRACE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t_loads = wall_clock64();
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // phase 2
     if (cnt == 8) skinny16_mfma<8>(a0, a1, b, acc0, acc1);
     else if (cnt == 4) skinny16_mfma<4>(a0, a1, b, acc0, acc1);
@@ -478,6 +488,7 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
     if (TRACE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tr[2] = wall_clock64();
+        if (lane == 0) { wave_t[wave][0] = t_loads; wave_t[wave][1] = tr[2]; }
     }
 
 #pragma unroll
@@ -517,10 +528,14 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
     if (TRACE && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tr[4] = wall_clock64();
-        const unsigned slot = atomicAdd(&g_trace_n, 1u);
-        if (slot < TRACE_SLOTS) {
-            for (int k = 0; k < 5; ++k) g_trace[(size_t)slot * 6 + k] = tr[k];
-            g_trace[(size_t)slot * 6 + 5] = ((unsigned long long)z << 48) | ((unsigned long long)tile << 32) |
+        const size_t slot = (size_t)(batch.start[7] % (int)TRACE_LAUNCHES) * TRACE_WGS + bx;   // no atomics: slot = (launch, workgroup)
+        if ((unsigned)bx < TRACE_WGS) {
+            for (int k = 0; k < 5; ++k) g_trace[(size_t)slot * TRACE_REC + k] = tr[k];
+            for (int k = 0; k < W; ++k) {
+                g_trace[(size_t)slot * TRACE_REC + 6 + 2 * k] = wave_t[k][0];
+                g_trace[(size_t)slot * TRACE_REC + 7 + 2 * k] = wave_t[k][1];
+            }
+            g_trace[(size_t)slot * TRACE_REC + 5] = ((unsigned long long)z << 48) | ((unsigned long long)tile << 32) |
                                             ((unsigned long long)I(SD_CNT) << 24) | (unsigned)(gridDim.x * gridDim.y * gridDim.z);
         }
     }
@@ -540,7 +555,9 @@ hipError_t skinny_init(int device) {   // called from ts_ctx_create (never durin
     g_zero[device] = z;
     if (getenv("TS_SKINNY_TRACE") && atoi(getenv("TS_SKINNY_TRACE"))) {
         unsigned long long *t = nullptr;
-        e = hipMalloc(&t, (size_t)TRACE_SLOTS * 6 * sizeof(unsigned long long));
+        e = hipMalloc(&t, TRACE_SLOTS * TRACE_REC * sizeof(unsigned long long));
+        if (e != hipSuccess) return e;
+        e = hipMemset(t, 0, TRACE_SLOTS * TRACE_REC * sizeof(unsigned long long));
         if (e != hipSuccess) return e;
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &t, sizeof(t));
         if (e != hipSuccess) return e;
@@ -646,8 +663,7 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
     // fatter workgroup.  TS_SKINNY_MAXW caps it (tuning).
     static const int maxw = [] { const char *e = getenv("TS_SKINNY_MAXW"); return e ? atoi(e) : 16; }();
     if (ncol == 16) {   // Q counts 8-k steps: K = 8 Q; the 16-column kernel keeps 8 accumulators -> at most 8 waves
-        static const int w_pref = [] { const char *e = getenv("TS_SKINNY_W"); return e ? atoi(e) : 8; }();
-        const int W16 = (Q >= 32 && maxw >= 8 && w_pref >= 8) ? 8 : 4;
+        const int W16 = (Q >= 32 && maxw >= 8) ? 8 : 4;
         static const int variant = [] { const char *e = getenv("TS_SKINNY_V"); return e ? atoi(e) : 1; }();
         int dev = 0;
         if (variant != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_zero[dev]) {
@@ -665,6 +681,7 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
                 const dim3 grid(total);
                 static const int trace = [] { const char *e = getenv("TS_SKINNY_TRACE"); return e ? atoi(e) : 0; }();
                 if (trace) {
+                    db.start[7] = (int)(g_trace_seq++);
                     if (W16 == 8) hipLaunchKernelGGL((skinny16_fast_kernel<8, true>), grid, dim3(512), 0, stream, db);
                     else hipLaunchKernelGGL((skinny16_fast_kernel<4, true>), grid, dim3(256), 0, stream, db);
                     return hipGetLastError();
@@ -688,16 +705,13 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
 
 // copies the TRACE records to the host and resets the counter; returns the number of records
 int skinny_trace_read(unsigned long long *out, int max_records) {
-    unsigned n = 0;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(n)) != hipSuccess) return -1;
-    if (n > TRACE_SLOTS) n = TRACE_SLOTS;
-    if ((int)n > max_records) n = max_records;
     unsigned long long *t = nullptr;
     if (hipMemcpyFromSymbol(&t, HIP_SYMBOL(g_trace), sizeof(t)) != hipSuccess || !t) return -1;
-    if (n && hipMemcpy(out, t, (size_t)n * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    const unsigned zero = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
-    return (int)n;
+    size_t n = (size_t)(g_trace_seq < TRACE_LAUNCHES ? g_trace_seq : TRACE_LAUNCHES) * TRACE_WGS;
+    if (n > (size_t)max_records) n = max_records;
+    if (n && hipMemcpy(out, t, n * TRACE_REC * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemset(t, 0, TRACE_SLOTS * TRACE_REC * sizeof(unsigned long long)) != hipSuccess) return -1;
+    return (int)n;   // slots (launch-major); empty slots are all zero
 }
 
 hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream) {

@@ -455,3 +455,20 @@ def test_device_mfcc_vs_host_restatement(hip, tmp_path):
     b = fe.get_mfcc_ta(p, sr=22000, fps=30, host=True)                         # numpy path
     assert a.shape == b.shape and a.shape[1] == 64
     np.testing.assert_allclose(a, b, atol=0.05, rtol=2e-4)
+
+
+@pytest.mark.parametrize("env", [{"TS_SKINNY_V": "0"}, {"TS_NO_GRAPH": "1"}, {"TS_SKINNY_NT": "32"}],
+                         ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel"])
+def test_alternate_kernel_paths(hip, env):
+    """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
+    launches, the 32-column kernel).  The knobs are read once per process, so the golden-vector tests are re-run in a child
+    process with each fallback forced: all paths must stay bit-exact on the codes."""
+    import subprocess
+    import sys
+    child_env = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q",
+                        "-k", "pixelcnn_golden or pixelcnn_sampling_and_prefix or single_layer_pixelcnn or op_linear"],
+                       env=child_env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

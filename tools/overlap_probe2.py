@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""CU partitioning probe: chains on CUs [0, NC), conv stacks on [NC, 256); independent work on both sides."""
+"""CU partitioning probe: conv stacks (VQ encode + decode of a batch) confined to CUs [NC, 256) on SV streams, PixelCNN
+chains of other batches on SC unrestricted streams.  Independent work on both sides; SC + SV <= 4 (more than four busy
+streams collapse on this stack)."""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
@@ -16,10 +18,10 @@ gt = torch.from_numpy(synth.gt_poses(2000, B, T)).to(dev)
 ids = torch.from_numpy(synth.speaker_ids(B)).to(dev)
 feat = w.audioencoder.forward_nlc(mfcc)
 torch.cuda.synchronize()
+ctx = _lib.context(0)
 
-def run(NC, SC, SV, n=16):
-    """NC CUs for the chain streams (0 = no masks), SC chain streams, SV conv streams."""
-    cs = _lib.create_streams(SC, 0, cus=(0, NC) if NC else None)
+def run(NC, SC, SV, n=24):
+    cs = _lib.create_streams(SC, 0)
     vs = _lib.create_streams(SV, 0, cus=(NC, 256 - NC) if NC else None)
     codes = [torch.empty((B, H, 2), dtype=torch.int64, device=dev) for _ in range(SV)]
     recon = [torch.empty((B, T, 129), dtype=torch.float32, device=dev) for _ in range(SV)]
@@ -40,7 +42,10 @@ def run(NC, SC, SV, n=16):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
     a, b, c = t([chain]), t([conv]), t([conv, chain])
-    print(f"NC={NC} chain_streams={SC} conv_streams={SV}: chain {a:.2f}  conv {b:.2f}  both {c:.2f} ms/batch", flush=True)
+    print(f"conv on CUs [{NC},256) x{SV} streams, {SC} chain streams: chain {a:.2f}  conv {b:.2f}  both {c:.2f} ms/batch", flush=True)
+    torch.cuda.synchronize()
+    for s_ in cs + vs:
+        lib.ts_stream_destroy(ctx, s_.cuda_stream)
 
-for cfg in [(0, 4, 2), (64, 4, 2), (32, 4, 2), (96, 4, 2), (64, 6, 2), (64, 4, 1), (128, 4, 2)]:
+for cfg in [(0, 3, 1), (64, 3, 1), (96, 3, 1), (32, 3, 1), (128, 3, 1)]:
     run(*cfg)

@@ -20,8 +20,9 @@ dev = torch.device("cuda", 0)
 mfcc = torch.from_numpy(synth.mfcc_features(1000, B, T)).to(dev)
 ids = torch.from_numpy(synth.speaker_ids(B)).to(dev)
 s = _lib.create_streams(1, 0)[0]
-CAP = 1 << 20
-buf = (C.c_uint64 * (6 * CAP))()
+CAP = 512 * 4096
+REC = 24
+buf = (C.c_uint64 * (REC * CAP))()
 with torch.cuda.stream(s):
     feat = w.audioencoder.forward_nlc(mfcc)
     for _ in range(2):
@@ -31,7 +32,9 @@ with torch.cuda.stream(s):
     w.generator.run(ids, feat, mode=_lib.TS_SAMPLE_GREEDY)
     torch.cuda.synchronize()
 n = lib.ts_debug_skinny_trace(buf, CAP)
-r = np.frombuffer(buf, dtype=np.uint64)[: n * 6].reshape(n, 6)
+r = np.frombuffer(buf, dtype=np.uint64)[: n * REC].reshape(n, REC)
+r = r[r[:, 0] > 0]
+n = len(r)
 meta = r[:, 5]
 t = r[:, :5].astype(np.int64) * 0.01               # microseconds
 dead = (meta >> np.uint64(63)).astype(bool)
@@ -65,3 +68,18 @@ for g in np.unique(R[:, 0]):
     x = R[m]
     print(f"  {int(g):4d} {int(np.median(x[:,1])):4d} {m.sum():6d}    | {np.median(x[:,2]):6.2f}          | {np.median(x[:,3]):6.2f}   | {np.median(x[:,4]):5.2f} / {np.median(x[:,5]):5.2f}"
           f"             | {np.median(x[:,8]):.2f}  {np.median(x[:,9]):.2f}  {np.median(x[:,10]):.2f}  {np.median(x[:,11]):.2f} | {np.median(period[mm]) if mm.any() else 0:.2f}")
+
+# per-wave view (workgroups of 8 waves): offsets from the workgroup's entry stamp
+wt = r[order][:, 6:22].astype(np.int64) * 0.01
+ent = t[:, 0:1]
+ld = wt[:, 0::2] - ent
+mf = wt[:, 1::2] - ent
+cntv = ((meta[order] >> np.uint64(24)) & np.uint64(0xff)).astype(np.int64)
+zv = (meta[order] >> np.uint64(48)).astype(np.int64) & 0x7fff
+for c in np.unique(cntv):
+    m = (cntv == c) & (wt[:, 14] > 0)
+    if not m.any():
+        continue
+    print(f"cnt={c} ({m.sum()} workgroups): per wave median [operands back | MFMAs done] us after entry")
+    print("   loads:", " ".join(f"{np.median(ld[m, k]):5.2f}" for k in range(8)))
+    print("   mfma :", " ".join(f"{np.median(mf[m, k]):5.2f}" for k in range(8)))
