@@ -190,9 +190,10 @@ static int pick_tile(const ConvParams &p) {
     // Cost model: the 256 CUs pull tiles dynamically, so a launch lasts about ceil(tiles / 256) tile-times on the busiest
     // CU; a tile-time is its MACs over the tile shape's measured intrinsic efficiency (tools/tune_conv.py on 4096^3:
     // 128x128 125 TF, 64x128 116, 128x64 112, 64x64 111).  Small / mid-size layers want many small tiles (tail), big ones
-    // the 128x128 tile (half the L2->LDS traffic per MAC).
+    // the 128x128 tile (half the L2->LDS traffic per MAC).  160x128 (one workgroup per CU, 0.79 alone) pays when it turns a
+    // launch into a single full wave: the paired body+hand layers of the VQ stacks at batch 32 are exactly 240 such tiles.
     struct Cand { int id, bm, bn; double eff; };
-    static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.89}, {3, 128, 64, 0.90}, {4, 64, 128, 0.93}};
+    static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.89}, {3, 128, 64, 0.90}, {4, 64, 128, 0.93}, {6, 160, 128, 0.93}};
     int best = 2;
     double best_cost = 1e300;
     for (const Cand &c : cands) {
@@ -215,6 +216,11 @@ hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream) {
         case 5:   // 64x64 with 64-deep chunks (all segment lengths must be multiples of 64)
             hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32, 64>), grid(64, 64), block, 0, stream, p);
             break;
+        // tall tiles, waves side by side along N (each 32 columns x the whole tile height): 160x128 turns the three big
+        // layer shapes of the VQ stacks at batch 32 (M*N = 2 x 2400x1024 = 2 x 4800x512 = 2 x 9600x256) into exactly 240
+        // tiles, one per CU in a single wave, with the L2->LDS traffic per MAC of the 128x128 tile
+        case 6: hipLaunchKernelGGL((conv_gemm_kernel<160, 128, 160, 32>), grid(160, 128), block, 0, stream, p); break;
+        case 7: hipLaunchKernelGGL((conv_gemm_kernel<96, 128, 96, 32>), grid(96, 128), block, 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -335,23 +335,23 @@ typedef __attribute__((address_space(1))) float gf;
 typedef __attribute__((address_space(1))) const int gci;
 typedef __attribute__((address_space(1))) const f32x4 gcf4;
 
-template <int CNT>
+template <int CNT, bool HALF>
 __device__ __forceinline__ void skinny16_load(gcf *ap0, gcf *ap1, gcf *bp, f32x4 (&a0)[8], f32x4 (&a1)[8], f32x4 (&b)[8]) {
 #pragma unroll
     for (int u = 0; u < CNT; ++u) {
         b[u] = *reinterpret_cast<gcf4 *>(bp + u * 16);
         a0[u] = *reinterpret_cast<gcf4 *>(ap0 + u * 16);
-        a1[u] = *reinterpret_cast<gcf4 *>(ap1 + u * 16);
+        if (!HALF) a1[u] = *reinterpret_cast<gcf4 *>(ap1 + u * 16);
     }
 }
-template <int CNT>
+template <int CNT, bool HALF>
 __device__ __forceinline__ void skinny16_mfma(const f32x4 (&a0)[8], const f32x4 (&a1)[8], const f32x4 (&b)[8], f32x4 &acc0, f32x4 &acc1) {
 #pragma unroll
     for (int u = 0; u < CNT; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u][e], b[u][e], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][e], b[u][e], acc1, 0, 0, 0);
+            if (!HALF) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][e], b[u][e], acc1, 0, 0, 0);
         }
 }
 
@@ -363,9 +363,14 @@ constexpr size_t TRACE_SLOTS = (size_t)TRACE_WGS * TRACE_LAUNCHES;
 __device__ unsigned long long *g_trace;   // [TRACE_SLOTS][TRACE_REC], allocated by skinny_init when TS_SKINNY_TRACE is set
 static unsigned g_trace_seq = 0;          // host: sequence number handed to the next traced launch
 
-template <int W, bool TRACE = false>
+// HALF: 16-row tiles (one MFMA row block): a workgroup fetches 16 instead of 32 activation rows — the A operand is 2/3 of a
+// 32-row workgroup's bytes and a stage is bounded by what one CU can fetch — used when the launch still fits one
+// workgroup per CU.
+template <int W, bool HALF = false, bool TRACE = false>
 __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescBatch batch) {
-    __shared__ float red[W][8][64];
+    constexpr int ROWS = HALF ? 16 : 32;
+    constexpr int NREG = HALF ? 4 : 8;          // accumulator registers per lane to reduce across the waves
+    __shared__ float red[W][NREG][64];
     __shared__ unsigned long long wave_t[TRACE ? W : 1][2];
     unsigned long long tr[5] = {0, 0, 0, 0, 0};
     if (TRACE) tr[0] = wall_clock64();
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
     gcf *base = P(sbase);
     gci *gidx = (gci *)P(sbase + 2);
     const int row_stride = I(sbase + 4), row_shift = I(sbase + 6);
-    const int m0 = mt * 32 + li, m1 = m0 + 16;
+    const int m0 = mt * ROWS + li, m1 = HALF ? m0 : m0 + 16;
     const int m0c = m0 < M ? m0 : M - 1, m1c = m1 < M ? m1 : M - 1;   // clamped rows: computed, never stored
     gcf *ar0, *ar1;
     if (gidx) {   // wave-uniform: token-embedding gather (one extra round trip, first stage of column 1 only)
@@ -447,13 +452,15 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
     gcf *bp = P(SD_W) + (long)nc * I(SD_LDW) + q0 * 16 + lg * 4;
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int RPW = 8 / W;
+    constexpr int RPW = NREG >= W ? NREG / W : 1;   // registers finished by each (active) wave
+    const bool active = wave * RPW < NREG;          // HALF with 8 waves: waves 4..7 only contribute partial sums
     float e_add[RPW], e_cls[RPW];
     auto epilogue_operands = [&]() {
+        if (!active) return;
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr;
-            const int row = mt * 32 + (r >> 2) * 16 + lg * 4 + (r & 3);
+            const int row = mt * ROWS + (r >> 2) * 16 + lg * 4 + (r & 3);
             const int rowc = row < M ? row : 0;
             const float t0 = P(SD_BIAS)[nc];
             const float t1 = P(SD_ADD1)[(long)(rowc >> I(SD_ADD1_SHIFT)) * I(SD_ADD1_STRIDE) + nc];
@@ -466,11 +473,11 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
     };
     // phase 1: every load of this wave — K operands first (they are waited for first), then the epilogue operands
     f32x4 a0[8], a1[8], b[8];
-    if (cnt == 8) skinny16_load<8>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
-    else if (cnt == 4) skinny16_load<4>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
-    else if (cnt == 2) skinny16_load<2>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
-    else if (cnt == 1) skinny16_load<1>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
-    else skinny16_load<3>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
+    if (cnt == 8) skinny16_load<8, HALF>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
+    else if (cnt == 4) skinny16_load<4, HALF>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
+    else if (cnt == 2) skinny16_load<2, HALF>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
+    else if (cnt == 1) skinny16_load<1, HALF>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
+    else skinny16_load<3, HALF>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
     epilogue_operands();
     __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from sinking loads between the MFMAs
     unsigned long long t_loads = 0;
@@ -480,11 +487,11 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
         __builtin_amdgcn_sched_barrier(0);
     }
     // phase 2
-    if (cnt == 8) skinny16_mfma<8>(a0, a1, b, acc0, acc1);
-    else if (cnt == 4) skinny16_mfma<4>(a0, a1, b, acc0, acc1);
-    else if (cnt == 2) skinny16_mfma<2>(a0, a1, b, acc0, acc1);
-    else if (cnt == 1) skinny16_mfma<1>(a0, a1, b, acc0, acc1);
-    else skinny16_mfma<3>(a0, a1, b, acc0, acc1);
+    if (cnt == 8) skinny16_mfma<8, HALF>(a0, a1, b, acc0, acc1);
+    else if (cnt == 4) skinny16_mfma<4, HALF>(a0, a1, b, acc0, acc1);
+    else if (cnt == 2) skinny16_mfma<2, HALF>(a0, a1, b, acc0, acc1);
+    else if (cnt == 1) skinny16_mfma<1, HALF>(a0, a1, b, acc0, acc1);
+    else skinny16_mfma<3, HALF>(a0, a1, b, acc0, acc1);
     if (TRACE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tr[2] = wall_clock64();
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         red[wave][r][lane] = acc0[r];
-        red[wave][4 + r][lane] = acc1[r];
+        if (!HALF) red[wave][4 + r][lane] = acc1[r];
     }
     __syncthreads();
     if (TRACE) tr[3] = wall_clock64();
@@ -502,12 +509,12 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
     gf *out = (gf *)P(SD_OUT);
     const int out_stride = I(SD_OUT_STRIDE);
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
+    for (int rr = 0; rr < (active ? RPW : 0); ++rr) {
         const int r = wave * RPW + rr;
         float v = red[0][r][lane];
 #pragma unroll
         for (int w = 1; w < W; ++w) v += red[w][r][lane];
-        const int row = mt * 32 + (r >> 2) * 16 + lg * 4 + (r & 3);
+        const int row = mt * ROWS + (r >> 2) * 16 + lg * 4 + (r & 3);
         const bool ok = n_ok && row < M;
         v += e_add[rr];
         if (gate) {
@@ -669,25 +676,34 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
         if (variant != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_zero[dev]) {
             SkinnyDescBatch db;
             bool fast = true;
+            // 16-row tiles when the launch then still fits one workgroup per CU (less to fetch per CU), else 32-row tiles
+            static const int half_max = [] { const char *e = getenv("TS_SKINNY_HALF_MAX"); return e ? atoi(e) : 256; }();
+            int total16 = 0;
+            for (int i = 0; i < n; ++i) total16 += b.p[i].grid_x * ((b.p[i].M + 15) / 16);
+            const bool half = total16 <= half_max;
             int total = 0;
             for (int i = 0; i < 8; ++i) db.start[i] = 0x7fffffff;
             for (int i = 0; i < n && fast; ++i) {
                 fast = skinny_pack_desc(b.p[i], W16, g_zero[dev], db.d[i]);
                 db.start[i] = total;
-                total += b.p[i].grid_x * b.p[i].grid_y;
+                total += b.p[i].grid_x * (half ? (b.p[i].M + 15) / 16 : b.p[i].grid_y);
             }
             for (int i = n; i < SKINNY_MAX_PROBLEMS; ++i) std::memset(&db.d[i], 0, sizeof(SkinnyDesc));
             if (fast) {
                 const dim3 grid(total);
                 static const int trace = [] { const char *e = getenv("TS_SKINNY_TRACE"); return e ? atoi(e) : 0; }();
-                if (trace) {
-                    db.start[7] = (int)(g_trace_seq++);
-                    if (W16 == 8) hipLaunchKernelGGL((skinny16_fast_kernel<8, true>), grid, dim3(512), 0, stream, db);
-                    else hipLaunchKernelGGL((skinny16_fast_kernel<4, true>), grid, dim3(256), 0, stream, db);
-                    return hipGetLastError();
+                if (trace) db.start[7] = (int)(g_trace_seq++);
+                const int sel = (W16 == 8 ? 0 : 4) + (half ? 2 : 0) + (trace ? 1 : 0);
+                switch (sel) {
+                    case 0: hipLaunchKernelGGL((skinny16_fast_kernel<8, false, false>), grid, dim3(512), 0, stream, db); break;
+                    case 1: hipLaunchKernelGGL((skinny16_fast_kernel<8, false, true>), grid, dim3(512), 0, stream, db); break;
+                    case 2: hipLaunchKernelGGL((skinny16_fast_kernel<8, true, false>), grid, dim3(512), 0, stream, db); break;
+                    case 3: hipLaunchKernelGGL((skinny16_fast_kernel<8, true, true>), grid, dim3(512), 0, stream, db); break;
+                    case 4: hipLaunchKernelGGL((skinny16_fast_kernel<4, false, false>), grid, dim3(256), 0, stream, db); break;
+                    case 5: hipLaunchKernelGGL((skinny16_fast_kernel<4, false, true>), grid, dim3(256), 0, stream, db); break;
+                    case 6: hipLaunchKernelGGL((skinny16_fast_kernel<4, true, false>), grid, dim3(256), 0, stream, db); break;
+                    default: hipLaunchKernelGGL((skinny16_fast_kernel<4, true, true>), grid, dim3(256), 0, stream, db); break;
                 }
-                if (W16 == 8) hipLaunchKernelGGL((skinny16_fast_kernel<8, false>), grid, dim3(512), 0, stream, db);
-                else hipLaunchKernelGGL((skinny16_fast_kernel<4, false>), grid, dim3(256), 0, stream, db);
                 return hipGetLastError();
             }
         }

@@ -66,6 +66,34 @@ def test_op_conv1d(hip, B, L, Cin, Cout, K, stride, tr, act):
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-5, rtol=1e-5)
 
 
+def test_conv_tile_shapes_agree(hip):
+    """Every tile shape of conv_gemm_f32 (64x64 ... 160x128) walks K in the same order, so the outputs must be bit-identical;
+    M = 225 and N = 200 are ragged against every tile height / width."""
+    _lib, lib, ctx = hip
+    rng = np.random.default_rng(77)
+    B, L, Cin, Cout, K = 3, 75, 64, 200, 3
+    x = rng.standard_normal((B, L, Cin)).astype(np.float32)
+    npad = (Cout + 127) // 128 * 128
+    w = np.zeros((npad, K * Cin), np.float32)
+    w[:Cout] = rng.standard_normal((Cout, K * Cin)).astype(np.float32) / np.sqrt(K * Cin)
+    b = np.zeros(npad, np.float32)
+    b[:Cout] = rng.standard_normal(Cout).astype(np.float32)
+    xp = np.pad(x, ((0, 0), (1, 1), (0, 0)))
+    ref = sum(xp[:, k:k + L, :] @ w[:Cout, k * Cin:(k + 1) * Cin].T for k in range(K)) + b[:Cout]
+    ref = np.where(ref >= 0, ref, 0.2 * ref).astype(np.float32)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    outs = {}
+    for tile in (1, 2, 3, 4, 5, 6, 7, 0):
+        out = torch.full((B, L, Cout), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, tile, 1,
+                                          _lib.dptr(out), None, None))
+        torch.cuda.synchronize()
+        outs[tile] = out.cpu().numpy()
+    np.testing.assert_allclose(outs[2], ref, atol=2e-5, rtol=1e-5)
+    for tile, o in outs.items():
+        assert np.array_equal(o, outs[2]), f"tile {tile} differs from the 64x64 tile"
+
+
 @pytest.mark.parametrize("M,ncode,dim", [(1, 128, 64), (13, 2048, 64), (2400, 2048, 64)])
 def test_op_vq_argmin(hip, M, ncode, dim):
     _lib, lib, ctx = hip
