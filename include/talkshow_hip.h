@@ -178,6 +178,13 @@ int ts_op_linear(ts_ctx *ctx, const float *x_dev, int M, int K, const float *w_h
 int ts_op_sample(ts_ctx *ctx, const float *logits_dev, int B, int V, int mode, const float *uniforms_dev,
                  int64_t *idx_dev, void *stream);
 
+/* Output assembly the callers do after both generators (scripts/demo.py:207-229 + data_utils/lower_body.py:68-87
+ * `part2full`): body_dev (B,Tb,129) body+hand poses, face_dev (B,Tf,103) jaw(3)+expression(100) -> out_dev (B,Tf,265).
+ * The body is aligned to the face length (last frame repeated, or trimmed); lower_pose33_host = the 33 fixed
+ * lower-body values part2full inserts (`lower_pose`, or zeros with [6:9] = global orientation when stand=True). */
+int ts_assemble_full(ts_ctx *ctx, const float *body_dev, int Tb, const float *face_dev, int Tf, int B,
+                     const float *lower_pose33_host, float *out_dev, void *stream);
+
 /* Tuning / roofline entry (not part of the drop-in surface): a stride-1 conv layer (K = 1 or 3, Cin % 32 == 0)
  * whose weights are ALREADY packed on the device as [round128(Cout)][K*Cin] (tap-major, k contiguous), launched
  * `iters` times between two HIP events recorded on `stream`; tile: 0 = production heuristic, 1 = 128x128,

@@ -362,6 +362,25 @@ def body_pixel_infer(mfcc, ids, sd_audio, sd_pix, sd_body, sd_hand, n_layers=15,
     return codes, np.ascontiguousarray(poses), feat
 
 
+def assemble_full(body, face, lower_pose33):
+    """Caller-side output assembly, `scripts/demo.py:207-229` + `data_utils/lower_body.py:68-87` (`part2full`).
+
+    body (B,Tb,129), face (B,Tf,103) = jaw(3) + expression(100) -> (B,Tf,265).  The body is padded with its last frame
+    or trimmed to the face length (demo.py:207-211), concatenated as jaw | body | expression (demo.py:225), then the four
+    lower-body blocks are inserted (lower_body.py:77-86).
+    """
+    B, Tb, _ = body.shape
+    Tf = face.shape[1]
+    if Tb < Tf:
+        body = np.concatenate([body, np.repeat(body[:, -1:], Tf - Tb, axis=1)], axis=1)
+    else:
+        body = body[:, :Tf]
+    p = np.concatenate([face[..., :3], body, face[..., 3:]], axis=-1)
+    lp = np.broadcast_to(np.asarray(lower_pose33, np.float32), (B, Tf, 33))
+    return np.concatenate([p[..., :3], lp[..., :15], p[..., 3:6], lp[..., 15:21], p[..., 6:9], lp[..., 21:27],
+                           p[..., 9:12], lp[..., 27:], p[..., 12:]], axis=-1).astype(np.float32)
+
+
 def body_vq_infer(poses129, sd_body, sd_hand):
     """`s2g_body_vq.TrainWrapper.infer_on_audio(initial_pose=gt)` core (`smplx_body_vq.py:254-281,293`).
 

@@ -47,6 +47,16 @@ int ts_stream_create_cus(ts_ctx *ctx, int cu_first, int cu_count, void **out) {
     *out = s;
     return 0;
 }
+// Output assembly after both generators (scripts/demo.py:207-229, data_utils/lower_body.py:68-87)
+int ts_assemble_full(ts_ctx *ctx, const float *body, int Tb, const float *face, int Tf, int B, const float *lower_pose33,
+                     float *out, void *stream) {
+    if (!ctx || !body || !face || !lower_pose33 || !out) return fail("ts_assemble_full: null argument");
+    if (B < 1 || Tb < 1 || Tf < 1) return fail("ts_assemble_full: empty input");
+    MiscScope ms(ctx, (hipStream_t)stream);
+    TS_HIP(launch_assemble_full(body, face, lower_pose33, B, Tb, Tf, out, (hipStream_t)stream));
+    return 0;
+}
+
 // tuning aid (TS_SKINNY_TRACE=1): in-kernel wall-clock stamps of the PixelCNN chain kernel, 6 u64 per record
 int ts_debug_skinny_trace(unsigned long long *out, int max_records) {
     if (!out) return -1;

@@ -126,6 +126,9 @@ hipError_t launch_gather_rows(const float *table, int ld_table, const int64_t *i
                               float *out, int ldo, hipStream_t stream);
 // dst[m][0..cpad) = src[m][0..c) then zeros
 hipError_t launch_pad_rows(const float *src, int lds, int c, float *dst, int ldd, int cpad, long M, hipStream_t stream);
+// (B,Tb,129) body/hand poses + (B,Tf,103) jaw/expression -> (B,Tf,265) full SMPL-X parameter rows (demo.py:207-229, part2full)
+hipError_t launch_assemble_full(const float *body, const float *face, const float *lower_pose33, int B, int Tb, int Tf,
+                                float *out, hipStream_t stream);
 // int64 -> int32 (labels, teacher-forced codes)
 hipError_t launch_i64_to_i32(const int64_t *src, int *dst, long n, hipStream_t stream);
 

@@ -150,6 +150,58 @@ hipError_t launch_pad_rows(const float *src, int lds_, int c, float *dst, int ld
     return hipGetLastError();
 }
 
+// Whole-body output assembly (scripts/demo.py:207-229 + data_utils/lower_body.py:68-87): per frame
+//   p232 = [jaw = face[0:3] | body/hand 129 (last frame repeated / trimmed to the face length) | expression = face[3:103]]
+//   out265 = [p[0:3] lp[0:15] p[3:6] lp[15:21] p[6:9] lp[21:27] p[9:12] lp[27:33] p[12:232]]
+// One thread per output element; pure copies, HBM-bound (1.9 KB per frame).
+struct AssembleParams {
+    const float *body;   // (B, Tb, 129)
+    const float *face;   // (B, Tf, 103)
+    float *out;          // (B, Tf, 265)
+    int B, Tb, Tf;
+    float lp[33];        // the fixed lower-body pose block
+};
+__global__ void assemble_full_kernel(const AssembleParams p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)p.B * p.Tf * 265;
+    if (i >= n) return;
+    const int c = (int)(i % 265);
+    const long bt = i / 265;
+    const int t = (int)(bt % p.Tf), b = (int)(bt / p.Tf);
+    // column of the 232-vector this output column copies, or -(k+1) for lower-pose constant k
+    int src;
+    if (c < 3) src = c;
+    else if (c < 18) src = -(c - 3 + 1);
+    else if (c < 21) src = c - 15;
+    else if (c < 27) src = -(15 + c - 21 + 1);
+    else if (c < 30) src = c - 21;
+    else if (c < 36) src = -(21 + c - 30 + 1);
+    else if (c < 39) src = c - 27;
+    else if (c < 45) src = -(27 + c - 39 + 1);
+    else src = c - 33;
+    float v;
+    if (src < 0) {
+        v = p.lp[-src - 1];
+    } else if (src < 3) {
+        v = p.face[((long)b * p.Tf + t) * 103 + src];
+    } else if (src < 132) {
+        const int tb = t < p.Tb ? t : p.Tb - 1;
+        v = p.body[((long)b * p.Tb + tb) * 129 + (src - 3)];
+    } else {
+        v = p.face[((long)b * p.Tf + t) * 103 + 3 + (src - 132)];
+    }
+    p.out[i] = v;
+}
+hipError_t launch_assemble_full(const float *body, const float *face, const float *lower_pose33, int B, int Tb, int Tf,
+                                float *out, hipStream_t stream) {
+    AssembleParams p;
+    p.body = body; p.face = face; p.out = out; p.B = B; p.Tb = Tb; p.Tf = Tf;
+    for (int k = 0; k < 33; ++k) p.lp[k] = lower_pose33[k];
+    const long n = (long)B * Tf * 265;
+    hipLaunchKernelGGL(assemble_full_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 __global__ void i64_to_i32_kernel(const int64_t *src, int *dst, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (int)src[i];

@@ -64,3 +64,36 @@ def generate_sharded(generate_fn, mfcc, ids, batch=32):
         probe = torch.zeros((0,), dtype=torch.float32)
         local = probe
     return local, (a, b)
+
+
+def whole_body_sharded(body, face, mfcc, ids, wav, face_ids, mode=None, seed=0, batch_body=32, batch_face=64, stand=False):
+    """BASELINE configs[4]: whole-body generation of N clips sharded over the ranks, one all-gather at the end.
+
+    body / face: the `nets.s2g_body_pixel` / `nets.s2g_face` wrappers of this rank (full weight replicas).
+    mfcc (N,T,64), ids (N,) int64 speaker indices, wav (N,S) 16 kHz samples, face_ids (N,4) one-hot / zero float vectors:
+    the GLOBAL inputs (a rank only touches its own block).  Each rank runs the body path in batches of `batch_body` and the
+    face path in batches of `batch_face` on its contiguous block, assembles (n_local, Tf, 265) rows on the GPU
+    (`pose_index.assemble_full` = demo.py:207-229 + part2full) and the ranks exchange them once.
+    Returns (all_rows (N,Tf,265) on every rank, (start, stop) of this rank's block).
+    """
+    from . import _lib
+    from .pose_index import assemble_full
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    n = mfcc.shape[0]
+    a, b = shard_range(n, rank, world)
+    frames = wav.shape[1] * 30 // 16000                       # smplx_face.py:203
+    mode = _lib.TS_SAMPLE_PHILOX if mode is None else mode
+    poses, faces = [], []
+    for s in range(a, b, batch_body):
+        e = min(s + batch_body, b)
+        poses.append(body.generate_batch(mfcc[s:e], ids[s:e], mode=mode, seed=seed, clip_index0=s)[1])
+    for s in range(a, b, batch_face):
+        e = min(s + batch_face, b)
+        faces.append(face.generator.run(wav[s:e], face_ids[s:e], frames))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if poses:
+        local = assemble_full(torch.cat(poses, 0), torch.cat(faces, 0), stand=stand)
+    else:
+        local = torch.zeros((0, frames, 265), dtype=torch.float32, device=dev)
+    return gather_sequences(local, n), (a, b)

@@ -255,6 +255,33 @@ def main():
         print("face_full: out", tuple(out.shape), "std", float(out.std()), "hidden std", float(hs.std()))
         save("face_full", wav=wav, ids=ids.numpy(), out=out.numpy(), hidden=hs.numpy(), generate_zero_id=gen.numpy())
 
+    # ---- 6. output assembly: demo.py:207-229 (length alignment + concat) and lower_body.part2full ------------------
+    if want("assemble_full"):
+        from data_utils.lower_body import part2full
+        rng = np.random.default_rng(41)
+        body = rng.standard_normal((2, 12, 129)).astype(np.float32)
+        outs = {}
+        for tag, Tf in (("longer_face", 15), ("shorter_face", 9)):
+            face = rng.standard_normal((2, Tf, 103)).astype(np.float32)
+            res = {False: [], True: []}
+            for b in range(2):
+                pred_face = torch.from_numpy(face[b])
+                pred_jaw, pred_exp = pred_face[:, :3], pred_face[:, 3:]          # demo.py:188-190
+                pred = torch.from_numpy(body[b])
+                if pred.shape[0] < pred_face.shape[0]:                            # demo.py:207-211
+                    repeat_frame = pred[-1].unsqueeze(dim=0).repeat(pred_face.shape[0] - pred.shape[0], 1)
+                    pred = torch.cat([pred, repeat_frame], dim=0)
+                else:
+                    pred = pred[:pred_face.shape[0], :]
+                pred = torch.cat([pred_jaw, pred, pred_exp], dim=-1)              # demo.py:225
+                for stand in (False, True):
+                    res[stand].append(part2full(pred, stand).numpy())             # demo.py:228
+            outs["face_" + tag] = face
+            outs["full_" + tag] = np.stack(res[False])
+            outs["full_stand_" + tag] = np.stack(res[True])
+        print("assemble_full:", {k: v.shape for k, v in outs.items()})
+        save("assemble_full", body=body, **outs)
+
     meta_path = os.path.join(HERE, "golden_meta.json")
     old = json.load(open(meta_path)) if os.path.exists(meta_path) else {"cases": {}}
     old["cases"].update(meta["cases"])

@@ -500,3 +500,45 @@ def test_alternate_kernel_paths(hip, env):
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_assemble_full(hip, golden):
+    """Device output assembly (ts_assemble_full) vs the reference's demo.py concat + part2full: pure copies, bit-exact."""
+    from talkshow_amd.pose_index import assemble_full
+    g = golden("assemble_full")
+    for tag in ("longer_face", "shorter_face"):
+        for stand, key in ((False, "full_"), (True, "full_stand_")):
+            out = assemble_full(g["body"], g["face_" + tag], stand=stand).cpu().numpy()
+            assert np.array_equal(out, g[key + tag]), (tag, stand)
+    with pytest.raises(ValueError):
+        assemble_full(np.zeros((2, 4, 128), np.float32), np.zeros((2, 4, 103), np.float32))
+    # BASELINE configs[4] shape: (32, 300, 129) + (32, 300, 103) -> (32, 300, 265), against the oracle
+    rng = np.random.default_rng(5)
+    body, face = rng.standard_normal((32, 300, 129)).astype(np.float32), rng.standard_normal((32, 300, 103)).astype(np.float32)
+    from talkshow_amd.pose_index import lower_pose_block
+    assert np.array_equal(assemble_full(body, face).cpu().numpy(), O.assemble_full(body, face, lower_pose_block(False)))
+
+
+def test_whole_body_sharded_single_rank(hip, tmp_path):
+    """configs[4] driver at world size 1: body batches + face batches + device assembly == the pieces run one by one."""
+    import types
+    import bench
+    from talkshow_amd import parallel
+    from talkshow_amd.modules import FaceGenerator
+    from talkshow_amd.pose_index import lower_pose_block
+    _lib, lib, ctx = hip
+    w, _ = bench.build_models(0)
+    m = FaceGenerator().cuda()
+    m.load_state_dict(synth.to_torch(synth.face_state_dict(seed=0)))
+    N, T, S = 5, 60, 32000                                   # 5 clips of 2 s: 60 body frames, 60 face frames
+    mfcc = dev(synth.mfcc_features(70, N, T))
+    ids = torch.from_numpy(synth.speaker_ids(N)).cuda()
+    wav = dev(synth.wav16(71, N, S))
+    fid = torch.nn.functional.one_hot(torch.arange(N) % 4, 4).float().cuda()
+    rows, (a, b) = parallel.whole_body_sharded(w, types.SimpleNamespace(generator=m), mfcc, ids, wav, fid,
+                                               mode=_lib.TS_SAMPLE_GREEDY, batch_body=2, batch_face=3)
+    assert (a, b) == (0, N) and rows.shape == (N, 60, 265)
+    poses = w.generate_batch(mfcc, ids, mode=_lib.TS_SAMPLE_GREEDY)[1].cpu().numpy()
+    face = m.run(wav, fid, 60).cpu().numpy()
+    ref = O.assemble_full(poses, face, lower_pose_block(False))
+    np.testing.assert_allclose(rows.cpu().numpy(), ref, atol=1e-5)

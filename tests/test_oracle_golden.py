@@ -99,3 +99,14 @@ def test_body_vq_e2e_full(golden):
                                  synth.vqvae_state_dict(seed=7, in_dim=90, salt=1))
     np.testing.assert_array_equal(codes, g["codes"])
     np.testing.assert_allclose(out, g["out"], atol=1e-4, rtol=0)
+
+
+def test_assemble_full(golden):
+    """demo.py:207-229 + part2full: jaw | body (aligned to the face length) | expression with the lower-body block inserted."""
+    from talkshow_amd.pose_index import lower_pose_block
+    g = golden("assemble_full")
+    for tag in ("longer_face", "shorter_face"):
+        for stand, key in ((False, "full_"), (True, "full_stand_")):
+            out = O.assemble_full(g["body"], g["face_" + tag], lower_pose_block(stand))
+            assert out.shape == g[key + tag].shape
+            assert np.array_equal(out, g[key + tag])
