@@ -104,6 +104,24 @@ def face_block(local):
             "other_kernels_ms": msf[2]}
 
 
+def diversity_block(w, _lib, mfcc1):
+    """BASELINE configs[3] as extra information: num_samples=12 stochastic decodes of ONE 10 s clip (Philox seed 2024)."""
+    B = 12
+    mf = mfcc1[:1].repeat(B, 1, 1).contiguous()
+    ids = torch.zeros(B, dtype=torch.int64, device=mf.device)
+    codes, _ = w.generate_batch(mf, ids, mode=_lib.TS_SAMPLE_PHILOX, seed=2024)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K = 3
+    for _ in range(K):
+        codes, poses = w.generate_batch(mf, ids, mode=_lib.TS_SAMPLE_PHILOX, seed=2024)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    distinct = len({c.cpu().numpy().tobytes() for c in codes})
+    return {"workload": "BASELINE configs[3]: 12 stochastic samples of one 10 s clip (Philox4x32-10, seed 2024), audio encoder -> PixelCNN -> VQ decode",
+            "frames_per_s": B * FRAMES_PER_CLIP / dt, "ms_per_call": dt * 1e3, "distinct_samples": distinct}
+
+
 def roofline_block(w, lib, _lib, stream, mfcc, ids, B, H, local, step):
     """Roofline of the dominant kernel + per-family breakdown.
 
@@ -260,6 +278,10 @@ def main():
     if rank == 0 and not a.no_roofline:
         out.update(roofline_block(w, lib, _lib, streams[0], mfcc[0], ids, B, H, local, step))
     if rank == 0 and not a.no_face:
+        try:
+            out["diversity"] = diversity_block(w, _lib, mfcc[0])
+        except Exception as e:
+            out["diversity"] = {"error": repr(e)}
         try:
             out["face"] = face_block(local)
         except Exception as e:                       # the face line is extra information; never lose the main line

@@ -118,22 +118,31 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 
     const int li = lane & 31, lh = lane >> 5;
 
-    // ---- K loop over (segment, 32-channel chunk), software pipelined ----
+    // ---- K loop over (segment, BK-channel chunk), software pipelined two chunks ahead ----
+    // iteration i: chunk i+1 (in registers since iteration i-1) goes to the idle LDS buffer, the global loads of chunk i+2
+    // are issued, then the MFMAs of chunk i run out of the other buffer.  The LDS writes and the global loads complete
+    // under the MFMA block, so the barrier at the end of the iteration has nothing slow left to wait for.
     int s = 0, tap = 0, cc = 0, kofs = 0;
+    const int nchunks = p.Ktot / BK;
+    auto advance = [&]() {
+        kofs += BK;
+        if (++cc * BK >= g.seg[s].len) {
+            cc = 0;
+            if (++tap >= g.seg[s].ntap) { tap = 0; ++s; }
+        }
+    };
     load_chunk(s, tap, cc, kofs);
     store_chunk(0);
+    if (nchunks > 1) {
+        advance();
+        load_chunk(s, tap, cc, kofs);
+    }
     __syncthreads();
     int buf = 0;
-    const int nchunks = p.Ktot / BK;
     for (int it = 0; it < nchunks; ++it) {
-        // advance to the next chunk and start its loads
-        bool has_next = it + 1 < nchunks;
-        if (has_next) {
-            kofs += BK;
-            if (++cc * BK >= g.seg[s].len) {
-                cc = 0;
-                if (++tap >= g.seg[s].ntap) { tap = 0; ++s; }
-            }
+        if (it + 1 < nchunks) store_chunk(buf ^ 1);
+        if (it + 2 < nchunks) {
+            advance();
             load_chunk(s, tap, cc, kofs);
         }
 #pragma unroll
@@ -153,7 +162,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
-        if (has_next) store_chunk(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }

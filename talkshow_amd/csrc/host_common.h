@@ -106,6 +106,8 @@ struct Profiler {
     struct Rec {
         hipEvent_t a, b;
         int fam;
+        double flops = 0;
+        std::string tag;   // TS_PROF_LOG=1: per-launch line printed by collect()
     };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;

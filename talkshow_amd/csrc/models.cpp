@@ -6,6 +6,7 @@
 //   vqvae_1d.AudioEncoder / Encoder nets/spg/vqvae_1d.py:11-34,66-92
 //   vqvae_1d.Decoder                nets/spg/vqvae_1d.py:116-149
 //   VectorQuantizerEMA (eval)       nets/spg/vqvae_modules.py:274-286,311-323
+#include <cstdio>
 #include "host_common.h"
 
 namespace ts {
@@ -38,6 +39,8 @@ int Profiler::collect() {
         TS_HIP(hipEventElapsedTime(&t, r.a, r.b));
         ms[r.fam] += t;
         launches[r.fam] += 1;
+        if (!r.tag.empty())
+            fprintf(stderr, "[ts_prof] %-56s %9.1f us %7.1f TF\n", r.tag.c_str(), t * 1e3, r.flops / (t * 1e-3) / 1e12);
         pool.push_back(r.a);
         pool.push_back(r.b);
     }
@@ -61,6 +64,14 @@ int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s) {
     if (ctx->prof.on) {
         ctx->prof.begin(FAM_CONV, s);
         ctx->prof.flops[FAM_CONV] += conv_gemm_flops(p);
+        static const bool log = getenv("TS_PROF_LOG") && atoi(getenv("TS_PROF_LOG"));
+        if (log) {
+            char buf[128];
+            snprintf(buf, sizeof(buf), "conv M=%d N=%d K=%d groups=%d z=%d stride=%d Lout=%d", p.M, p.N, p.Ktot, p.ngroups, p.zdiv,
+                     p.stride, p.Lout);
+            ctx->prof.recs.back().tag = buf;
+            ctx->prof.recs.back().flops = conv_gemm_flops(p);
+        }
     }
     hipError_t e = launch_conv_gemm(p, tile, s);
     if (ctx->prof.on) ctx->prof.end(s);

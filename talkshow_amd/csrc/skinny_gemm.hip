@@ -2,14 +2,19 @@
 //
 // One launch = one dependent stage of GatedMaskedConv2d / the logits head evaluated at ONE code position for the
 // whole batch of clips (reference: nets/spg/gated_pixelcnn_v2.py:61-87,120-124,137-144): M = B (or 2B) rows,
-// N = 256..2048 output channels, K = 256..1536.  The chain is latency bound (≈5k dependent stages per batch), so
-// the kernel is built to be SHORT rather than to stream: a workgroup owns 32 output columns for all rows, its
-// W (4/8/16) waves split K, every wave issues all of its 16-byte operand loads up front (operands go straight
-// from L2 to VGPRs — a weight row is read by exactly one lane, LDS staging would only add a round trip), runs its
-// share of v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains), and the partial 32x32 tiles are summed through LDS in
-// a fixed order (deterministic).  Epilogues fuse bias, an additive term (v->h contribution / residual / audio
-// term), the class conditioning and the tanh*sigmoid gate: the tile's columns are 16 "tanh" channels followed by
-// their 16 "sigmoid" partners, so the gate is one cross-lane exchange (lane ^ 16).
+// N = 256..2048 output channels, K = 256..512, up to 6 independent problems per launch.  The chain is latency bound
+// (≈2.8k dependent launches per batch), so the kernels are built to be SHORT rather than to stream: a workgroup owns
+// a 16- or 32-column tile, its waves split K, operands go straight from L2 to VGPRs (a weight row is read by exactly
+// one lane; LDS staging would only add a round trip), v_mfma_f32_{16x16x4,32x32x2}_f32 are exact fp32 fmaf chains,
+// and the partial tiles are summed through LDS in a fixed order (deterministic).  Epilogues fuse bias, additive
+// terms (v->h contribution / residual / audio term), the class conditioning and the tanh*sigmoid gate: a tile's
+// columns are "tanh" channels followed by their "sigmoid" partners, so the gate is one cross-lane exchange.
+//
+// Three kernels, one contract (bit-identical results):
+//   skinny16_fast_kernel  production path: 64-dword problem descriptors, branch-free loads, exact 1-D grid, 16- or
+//                         32-row tiles (see the comment above it; tools/skinny_trace.py is its in-kernel profiler)
+//   skinny16_kernel       generic 16-column kernel: any K multiple of 16, any segment layout (small / odd models)
+//   skinny_gemm_kernel    generic 32-column kernel on the 32x32x2 MFMA: K multiple of 8
 #include <cstdlib>
 #include <cstring>
 #include <cstdint>
