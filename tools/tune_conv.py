@@ -17,6 +17,8 @@ B = int(os.environ.get("TS_B", "32"))
 shapes = [(75, 1024, 1024, 3), (150, 512, 512, 3), (300, 256, 256, 3), (300, 64, 64, 3), (150, 128, 128, 3), (75, 256, 256, 3),
           (75 * 32 // B, 64, 1024, 1), (128, 4096, 4096, 1), (600, 768, 768, 1), (600, 768, 3072, 1), (600, 3072, 768, 1),
           (15999, 512, 512, 3)]
+if os.environ.get("TS_TUNE_FEW"):
+    shapes = [(75, 1024, 1024, 3), (150, 512, 512, 3), (300, 256, 256, 3), (128, 4096, 4096, 1), (600, 768, 3072, 1)]
 names = {0: "auto", 1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 5: "64x64k64", 6: "160x128", 7: "96x128"}
 for (L, Cin, Cout, K) in shapes:
     x = torch.randn(B, L, Cin, device="cuda")
