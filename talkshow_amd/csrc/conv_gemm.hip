@@ -75,27 +75,81 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
     const float *wbase = gw + (long)(n0 + lrow) * ldw + lc4;
 
-    f32x4 ra[PA][KC], rb[PB][KC];
-    auto load_chunk = [&](int s, int tap, int cc, int kofs) {
-        const int d = g.seg[s].d + tap;
-        const int coff = g.seg[s].c0 + cc * BK + lc4;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ================= pipelined main loop =================
+    // The MFMA pipe is only full if the few dozen non-MFMA instructions of a K chunk fit between the MFMAs, so this loop
+    // keeps them few and lets the scheduler spread them:
+    //   * per-thread operand POINTERS advance by one chunk (128 B) per iteration; they are recomputed only when the walk
+    //     enters the next tap / segment (a wave-uniform branch, every len/BK chunks);
+    //   * halo rows, rows beyond M and weight rows beyond w_rows point into a zero buffer instead of being predicated
+    //     or selected: every load is unconditional and nothing is patched afterwards;
+    //   * segment descriptors live in VGPR lanes (v_readlane): no scalar loads competing with LDS for lgkmcnt;
+    //   * MFMA fragments are double-buffered: the fragments of q+1 are read while the MFMAs of q run, and the first
+    //     fragments of the next chunk are read right after the barrier, under the last MFMA group of this chunk.
+    constexpr int NQ = BK / 8;
+    int vd = 0, vc0 = 0, vlen = BK, vnt = 1;
+    if (lane < 4) {
+        vd = g.seg[lane].d;
+        vc0 = g.seg[lane].c0;
+        vlen = g.seg[lane].len;
+        vnt = g.seg[lane].ntap > 1 ? g.seg[lane].ntap : 1;
+    }
+    const float *zero = p.zero + lc4;
+    int s = 0, tap = 0, cc = 0;
+    int cur_len = __builtin_amdgcn_readlane(vlen, 0), cur_nt = __builtin_amdgcn_readlane(vnt, 0);
+    const float *pa[PA], *pb[PB];
+    auto enter_run = [&]() {   // operand pointers of the first chunk of (segment s, tap)
+        const int sl = s & 3;
+        const int d = __builtin_amdgcn_readlane(vd, sl) + tap;
+        const int c0 = __builtin_amdgcn_readlane(vc0, sl);
+        cur_len = __builtin_amdgcn_readlane(vlen, sl);
+        cur_nt = __builtin_amdgcn_readlane(vnt, sl);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            int it = a_t[i] + d;
+            const int it = a_t[i] + d;
             const bool ok = a_rowbase[i] >= 0 && it >= 0 && it < p.Lin;
-#pragma unroll
-            for (int c = 0; c < KC; ++c)
-                ra[i][c] = ok ? *reinterpret_cast<const f32x4 *>(gx + (a_rowbase[i] + it) * p.ldx + coff + c * 32)
-                              : f32x4{0.f, 0.f, 0.f, 0.f};
+            pa[i] = ok ? gx + (a_rowbase[i] + it) * p.ldx + c0 + lc4 : zero;
         }
+    };
+    enter_run();
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const bool ok = n0 + i * 32 + lrow < w_rows;
+    for (int i = 0; i < PB; ++i) pb[i] = n0 + i * 32 + lrow < w_rows ? wbase + (long)i * 32 * ldw : zero;
+    auto advance = [&]() {
+        cc += 1;
 #pragma unroll
-            for (int c = 0; c < KC; ++c)
-                rb[i][c] = ok ? *reinterpret_cast<const f32x4 *>(wbase + (long)i * 32 * ldw + kofs + c * 32)
-                              : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < PB; ++i) pb[i] += BK;
+        if (cc * BK >= cur_len) {   // wave-uniform: next tap or next segment
+            cc = 0;
+            tap += 1;
+            if (tap >= cur_nt) {
+                tap = 0;
+                s += 1;
+            }
+            enter_run();
+        } else {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) pa[i] += BK;
         }
+    };
+    f32x4 ra[PA][KC], rb[PB][KC];
+    auto load_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) ra[i][c] = *reinterpret_cast<const f32x4 *>(pa[i] + c * 32);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) rb[i][c] = *reinterpret_cast<const f32x4 *>(pb[i] + c * 32);
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
@@ -107,62 +161,67 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) *reinterpret_cast<f32x4 *>(&Bs[buf][i * 32 + lrow][lc4 + c * 32]) = rb[i][c];
     };
-
-    f32x16 acc[TM][TN];
+    f32x4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](int buf, int q, int slot) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
+            fa[slot][i] = *reinterpret_cast<const f32x4 *>(&As[buf][wm * WM + i * 32 + li][q * 8 + lh * 4]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int li = lane & 31, lh = lane >> 5;
-
-    // ---- K loop over (segment, BK-channel chunk), software pipelined two chunks ahead ----
-    // iteration i: chunk i+1 (in registers since iteration i-1) goes to the idle LDS buffer, the global loads of chunk i+2
-    // are issued, then the MFMAs of chunk i run out of the other buffer.  The LDS writes and the global loads complete
-    // under the MFMA block, so the barrier at the end of the iteration has nothing slow left to wait for.
-    int s = 0, tap = 0, cc = 0, kofs = 0;
-    const int nchunks = p.Ktot / BK;
-    auto advance = [&]() {
-        kofs += BK;
-        if (++cc * BK >= g.seg[s].len) {
-            cc = 0;
-            if (++tap >= g.seg[s].ntap) { tap = 0; ++s; }
-        }
+            fb[slot][j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][wn * WN + j * 32 + li][q * 8 + lh * 4]);
     };
-    load_chunk(s, tap, cc, kofs);
+    auto mfma_q = [&](int slot) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][e], fb[slot][j][e], acc[i][j], 0, 0, 0);
+    };
+    const int nchunks = p.Ktot / BK;
+    load_chunk();
     store_chunk(0);
     if (nchunks > 1) {
         advance();
-        load_chunk(s, tap, cc, kofs);
+        load_chunk();
     }
     __syncthreads();
+    read_frags(0, 0, 0);
     int buf = 0;
-    for (int it = 0; it < nchunks; ++it) {
-        if (it + 1 < nchunks) store_chunk(buf ^ 1);
-        if (it + 2 < nchunks) {
-            advance();
-            load_chunk(s, tap, cc, kofs);
+    int it = 0;
+    for (; it + 2 < nchunks; ++it) {   // steady state: chunk it+1 -> LDS, chunk it+2 -> registers, MFMAs of chunk it
+        advance();
+        store_chunk(buf ^ 1);
+        load_chunk();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) {
+                read_frags(buf, q + 1, (q + 1) & 1);
+            } else {
+                __syncthreads();
+                read_frags(buf ^ 1, 0, 0);
+            }
+            mfma_q(q & 1);
+            // the LDS writes and the global loads of this iteration must be issued within the first MFMA group: left to
+            // itself the scheduler sinks the loads to the end of the iteration and the next one stalls on them
+            if (q == 0) __builtin_amdgcn_sched_barrier(0);
         }
+        buf ^= 1;
+    }
+    for (; it < nchunks; ++it) {       // last two chunks: nothing left to load
+        const bool has_next = it + 1 < nchunks;
+        if (has_next) store_chunk(buf ^ 1);
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            f32x4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4 *>(&As[buf][wm * WM + i * 32 + li][q * 8 + lh * 4]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][wn * WN + j * 32 + li][q * 8 + lh * 4]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) {
+                read_frags(buf, q + 1, (q + 1) & 1);
+            } else {
+                __syncthreads();
+                if (has_next) read_frags(buf ^ 1, 0, 0);
+            }
+            mfma_q(q & 1);
         }
-        __syncthreads();
         buf ^= 1;
     }
 
@@ -198,10 +257,10 @@ static int pick_tile(const ConvParams &p) {
     // Cost model: the 256 CUs pull tiles dynamically, so a launch lasts about ceil(tiles / 256) tile-times on the busiest
     // CU; a tile-time is its MACs over the tile shape's measured intrinsic efficiency (tools/tune_conv.py on 4096^3:
     // 128x128 125 TF, 64x128 116, 128x64 112, 64x64 111).  Small / mid-size layers want many small tiles (tail), big ones
-    // the 128x128 tile (half the L2->LDS traffic per MAC).  160x128 (one workgroup per CU, 0.79 alone) pays when it turns a
-    // launch into a single full wave: the paired body+hand layers of the VQ stacks at batch 32 are exactly 240 such tiles.
+    // the 128x128 tile (half the L2->LDS traffic per MAC).  The tall 160x128 / 96x128 tiles (tile ids 6, 7) stay available
+    // for tuning: one full wave of 240 tiles on the paired VQ layers ties with five waves of 64x64 tiles at best.
     struct Cand { int id, bm, bn; double eff; };
-    static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.89}, {3, 128, 64, 0.90}, {4, 64, 128, 0.93}, {6, 160, 128, 0.93}};
+    static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.93}, {3, 128, 64, 0.88}, {4, 64, 128, 0.90}};
     int best = 2;
     double best_cost = 1e300;
     for (const Cand &c : cands) {
@@ -212,10 +271,16 @@ static int pick_tile(const ConvParams &p) {
     return best;
 }
 
-hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream) {
+hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream) {
+    ConvParams p = p_in;
+    if (!p.zero) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) p.zero = skinny_zero_buffer(dev);
+    }
     if (tile == 0) tile = pick_tile(p);
     dim3 block(256);
     auto grid = [&](int bm, int bn) { return dim3((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, p.ngroups); };
+    if (!p.zero || p.g[0].nseg > 4) return hipErrorInvalidValue;   // zero buffer: ts::skinny_init (ts_ctx_create)
     switch (tile) {
         case 1: hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 64, 64>), grid(128, 128), block, 0, stream, p); break;
         case 2: hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32>), grid(64, 64), block, 0, stream, p); break;

@@ -45,6 +45,7 @@ struct ConvParams {
     int w_rows;          // number of valid weight rows (0 = padded to the grid); rows beyond read as zero
     // batched mode (zdiv > 0): blockIdx.z = z0*zdiv + z1 indexes independent problems that share g[0]'s geometry;
     // pointers advance by z0*zs0 + z1*zs1 floats
+    const float *zero;   // >= 64 KB of zeros (filled by the launcher): where halo / padding operand pointers are parked
     int zdiv;
     long x_zs0, x_zs1, w_zs0, w_zs1, o_zs0, o_zs1, b_zs1, r_zs0, r_zs1;
 };
@@ -110,6 +111,8 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
 // allocates the per-device zero buffer the fast skinny kernel substitutes for absent operands (call once per device,
 // outside stream capture; without it the generic kernels are used)
 hipError_t skinny_init(int device);
+// the per-device zero buffer (256 KB) allocated by skinny_init, or nullptr
+const float *skinny_zero_buffer(int device);
 // TS_SKINNY_TRACE=1 instrumentation: records of 6 u64 {t_entry, t_desc, t_mfma_done, t_reduced, t_end, cnt<<32|workgroups}
 int skinny_trace_read(unsigned long long *out, int max_records);
 

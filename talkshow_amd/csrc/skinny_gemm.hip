@@ -577,6 +577,8 @@ hipError_t skinny_init(int device) {   // called from ts_ctx_create (never durin
     return hipSuccess;
 }
 
+const float *skinny_zero_buffer(int device) { return device >= 0 && device < 16 ? g_zero[device] : nullptr; }
+
 static inline void put_ptr(SkinnyDesc &d, int k, const void *p) {
     const uint64_t v = (uint64_t)(uintptr_t)p;
     d.w[k] = (uint32_t)v;
