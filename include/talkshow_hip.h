@@ -188,13 +188,13 @@ int ts_assemble_full(ts_ctx *ctx, const float *body_dev, int Tb, const float *fa
 /* Tuning / roofline entry (not part of the drop-in surface): a stride-1 conv layer (K = 1 or 3, Cin % 32 == 0)
  * whose weights are ALREADY packed on the device as [round128(Cout)][K*Cin] (tap-major, k contiguous), launched
  * `iters` times between two HIP events recorded on `stream`; tile: 0 = production heuristic, 1 = 128x128,
- * 2 = 64x64, 3 = 128x64, 4 = 64x128.  *ms_out = mean launch duration in milliseconds. */
+ * 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 with 64-deep K chunks, 6 = 160x128, 7 = 96x128.  *ms_out = mean launch duration in milliseconds. */
 int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
                        const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
                        void *stream);
 
 /* Tuning entry (not part of the drop-in surface): `iters` DEPENDENT skinny_gemm launches replayed from one hipGraph;
- * *us_out = microseconds per launch.  gate != 0: N = 2K with the tanh*sigmoid epilogue; debug: ablation bits. */
+ * *us_out = microseconds per launch.  gate != 0: N = 2K with the tanh*sigmoid epilogue; debug: unused. */
 int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int debug, float *us_out);
 
 /* ---- instrumentation ---------------------------------------------------------------------------------------- */

@@ -217,7 +217,7 @@ int ts_op_linear(ts_ctx *ctx, const float *x, int M, int K, const float *w, cons
 
 // Tuning entry (not part of the drop-in surface): `iters` DEPENDENT skinny_gemm launches (stage i reads stage i-1's
 // output) captured in one hipGraph and replayed; *us_out = microseconds per launch.  M x K activations, N = K outputs
-// (linear) or 2K (gate epilogue, so the chain closes on itself); debug = ablation bits of skinny_gemm_kernel_v2.
+// (linear) or 2K (gate epilogue, so the chain closes on itself); `debug` is unused (kept for ABI stability).
 int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int debug, float *us_out) {
     if (!ctx || !us_out) return fail("ts_debug_skinny_chain: null argument");
     const int N = gate ? 2 * K : K;

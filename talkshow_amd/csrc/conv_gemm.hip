@@ -15,8 +15,9 @@
 //   * each lane fetches 4 consecutive k with one ds_read_b128 and feeds them to 4 consecutive MFMAs; the two lane
 //     halves take k {0..3} and {4..7} of every group of 8 — a permutation of the K order applied identically to A
 //     and B, so the product is unchanged and LDS traffic is 1 b128 per 4 MFMA per operand tile.
-//   * global -> register -> LDS double buffering: the next chunk's 16-byte coalesced loads are in flight while the
-//     current chunk's MFMAs issue; one barrier per chunk.
+//   * global -> register -> LDS pipeline two chunks deep: while the MFMAs of chunk i run, chunk i+1 is written to the idle
+//     LDS buffer and the 16-byte coalesced loads of chunk i+2 are in flight; one barrier per chunk; MFMA fragments are
+//     double-buffered in registers (see the comment at the main loop for how the non-MFMA instruction count is kept low).
 //   * convolution taps / stride / transposed-conv phases are "segments": (row shift, channel range) pairs, so only
 //     valid taps are multiplied (no zero-insertion for ConvTranspose, no wasted taps for stride 2).
 #include "kernels.h"

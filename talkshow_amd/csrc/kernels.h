@@ -50,7 +50,7 @@ struct ConvParams {
     long x_zs0, x_zs1, w_zs0, w_zs1, o_zs0, o_zs1, b_zs1, r_zs0, r_zs1;
 };
 
-// tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128 (for tuning / tests)
+// tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 (BK 64), 6 = 160x128, 7 = 96x128 (for tuning / tests)
 hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream);
 double conv_gemm_flops(const ConvParams &p);
 
