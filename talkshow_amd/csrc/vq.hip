@@ -10,6 +10,8 @@
 
 namespace ts {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------------------------------------------
 // vq_argmin: one workgroup = ROWS query rows x all codes.  Queries sit in LDS; each thread walks codes
 // j = tid, tid+256, ... (ascending, so a strict '<' keeps the lowest index on ties), reading the code row as
@@ -239,20 +241,46 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *lg = p.logits + (long)b * p.V;
 
-    if (p.logits_copy)
-        for (int v = tid; v < p.V; v += 256) p.logits_copy[(long)b * p.copy_stride + v] = lg[v];
+    // Every thread owns `chunk` consecutive logits [v0, v1).  For the production vocabulary (V = 2048: chunk = 8) they are
+    // fetched up front with two 16-byte loads — this kernel sits on the dependent chain, and a load-per-iteration loop
+    // costs one memory round trip per element.
+    const int chunk = (p.V + 255) / 256;
+    const int v0 = tid * chunk, v1 = min(v0 + chunk, p.V);
+    const bool fast = chunk == 8 && (p.V & 7) == 0;
+    float x[8];
+    if (fast) {
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(lg + v0), hi = *reinterpret_cast<const f32x4 *>(lg + v0 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x[k] = lo[k]; x[4 + k] = hi[k]; }
+    }
+
+    if (p.logits_copy) {
+        float *dst = p.logits_copy + (long)b * p.copy_stride;
+        if (fast) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[v0 + k] = x[k];
+        } else {
+            for (int v = v0; v < v1; ++v) dst[v] = lg[v];
+        }
+    }
 
     if (p.mode == TS_TEACHER_FORCED) {
         if (tid == 0) p.tok32[(long)b * p.tok_stride] = (int)p.codes[(long)b * p.code_stride];
         return;
     }
 
-    // ---- max / argmax (needed by both modes) ----
+    // ---- max / argmax (needed by both modes); ties -> lowest index ----
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int v = tid; v < p.V; v += 256) {
-        const float x = lg[v];
-        if (x > best) { best = x; bi = v; }
+    if (fast) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (x[k] > best) { best = x[k]; bi = v0 + k; }
+    } else {
+        for (int v = v0; v < v1; ++v) {
+            const float t = lg[v];
+            if (t > best) { best = t; bi = v; }
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -280,10 +308,13 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
                           (uint32_t)(seed >> 32), r);
             u = (float)(r >> 8) * (1.0f / 16777216.0f);
         }
-        const int chunk = (p.V + 255) / 256;
-        const int v0 = tid * chunk, v1 = min(v0 + chunk, p.V);
         float s = 0.f;
-        for (int v = v0; v < v1; ++v) s += expf(lg[v] - best);
+        if (fast) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += expf(x[k] - best);
+        } else {
+            for (int v = v0; v < v1; ++v) s += expf(lg[v] - best);
+        }
         sf[tid + 1] = s;
         __syncthreads();
         if (tid == 0) {
@@ -299,9 +330,18 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
         if (mine && v0 < p.V) {
             float c = sf[tid];
             int k = v1 - 1;
-            for (int v = v0; v < v1; ++v) {
-                c += expf(lg[v] - best);
-                if (c > thr) { k = v; break; }
+            if (fast) {
+                bool found = false;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {   // same running sum as the loop below; the first crossing is latched
+                    c += expf(x[j] - best);
+                    if (!found && c > thr) { k = v0 + j; found = true; }
+                }
+            } else {
+                for (int v = v0; v < v1; ++v) {
+                    c += expf(lg[v] - best);
+                    if (c > thr) { k = v; break; }
+                }
             }
             si[0] = k;
         } else if (mine) {
