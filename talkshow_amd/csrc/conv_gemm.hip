@@ -281,7 +281,8 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
     if (tile == 0) tile = pick_tile(p);
     dim3 block(256);
     auto grid = [&](int bm, int bn) { return dim3((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, p.ngroups); };
-    if (!p.zero || p.g[0].nseg > 4) return hipErrorInvalidValue;   // zero buffer: ts::skinny_init (ts_ctx_create)
+    // zero buffer (ts::skinny_init, called by ts_ctx_create): 64 Ki floats; parked pointers walk at most Ktot floats of it
+    if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000) return hipErrorInvalidValue;
     switch (tile) {
         case 1: hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 64, 64>), grid(128, 128), block, 0, stream, p); break;
         case 2: hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32>), grid(64, 64), block, 0, stream, p); break;
