@@ -27,6 +27,7 @@ namespace ts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;   // LDS-qualified: volatile accesses must not fall back to flat
 
 template <int BM, int BN, int WM, int WN, int BK = 32>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
@@ -165,11 +166,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     f32x4 fa[2][TM], fb[2][TN];
     auto read_frags = [&](int buf, int q, int slot) {
 #pragma unroll
+        // volatile: keeps each fragment ONE ds_read_b128.  Left alone the compiler splits the vector load into
+        // ds_read2_b32 pieces, and 32-bit reads of a 32-row column conflict 2-way on any 16-byte-aligned row pitch
+        // (rows li and li+16 share a bank); the 128-bit read is served 16 lanes at a time and is conflict free.
         for (int i = 0; i < TM; ++i)
-            fa[slot][i] = *reinterpret_cast<const f32x4 *>(&As[buf][wm * WM + i * 32 + li][q * 8 + lh * 4]);
+            fa[slot][i] = *(const volatile lds_f32x4 *)__builtin_assume_aligned(&As[buf][wm * WM + i * 32 + li][q * 8 + lh * 4], 16);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            fb[slot][j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][wn * WN + j * 32 + li][q * 8 + lh * 4]);
+            fb[slot][j] = *(const volatile lds_f32x4 *)__builtin_assume_aligned(&Bs[buf][wn * WN + j * 32 + li][q * 8 + lh * 4], 16);
     };
     auto mfma_q = [&](int slot) {
 #pragma unroll
@@ -257,15 +261,17 @@ double conv_gemm_flops(const ConvParams &p) { return 2.0 * p.M * (double)p.N * p
 static int pick_tile(const ConvParams &p) {
     // Cost model: the 256 CUs pull tiles dynamically, so a launch lasts about ceil(tiles / 256) tile-times on the busiest
     // CU; a tile-time is its MACs over the tile shape's measured intrinsic efficiency (tools/tune_conv.py on 4096^3:
-    // 128x128 125 TF, 64x128 116, 128x64 112, 64x64 111).  Small / mid-size layers want many small tiles (tail), big ones
-    // the 128x128 tile (half the L2->LDS traffic per MAC).  The tall 160x128 / 96x128 tiles (tile ids 6, 7) stay available
-    // for tuning: one full wave of 240 tiles on the paired VQ layers ties with five waves of 64x64 tiles at best.
+    // 128x128 134 TF, 128x64 / 64x128 129, 64x64 123).  Small / mid-size layers want many small tiles (tail), big ones
+    // the 128x128 tile (half the L2->LDS traffic per MAC).  The tall 160x128 tile runs one workgroup per CU: worth it
+    // only when it turns a launch with a long K into a single full wave (the paired 1024-channel VQ layers at batch 32
+    // are exactly 240 such tiles: 109 vs 102 TF); its un-overlapped prologue / epilogue lose on shorter K.
     struct Cand { int id, bm, bn; double eff; };
-    static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.93}, {3, 128, 64, 0.88}, {4, 64, 128, 0.90}};
+    static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.92}, {3, 128, 64, 0.95}, {4, 64, 128, 0.95}, {6, 160, 128, 0.99}};
     int best = 2;
     double best_cost = 1e300;
     for (const Cand &c : cands) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * p.ngroups;
+        if (c.id == 6 && (p.Ktot < 2048 || tiles > 256)) continue;
         const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
         if (cost < best_cost) { best_cost = cost; best = c.id; }
     }
