@@ -262,16 +262,16 @@ static int pick_tile(const ConvParams &p) {
     // Cost model: the 256 CUs pull tiles dynamically, so a launch lasts about ceil(tiles / 256) tile-times on the busiest
     // CU; a tile-time is its MACs over the tile shape's measured intrinsic efficiency (tools/tune_conv.py on 4096^3:
     // 128x128 134 TF, 128x64 / 64x128 129, 64x64 123).  Small / mid-size layers want many small tiles (tail), big ones
-    // the 128x128 tile (half the L2->LDS traffic per MAC).  The tall 160x128 tile runs one workgroup per CU: worth it
-    // only when it turns a launch with a long K into a single full wave (the paired 1024-channel VQ layers at batch 32
-    // are exactly 240 such tiles: 109 vs 102 TF); its un-overlapped prologue / epilogue lose on shorter K.
+    // the 128x128 tile (half the L2->LDS traffic per MAC).  The tall 160x128 / 96x128 tiles (ids 6, 7) stay available for
+    // tuning: 160x128 turns the paired 1024-channel VQ layers at batch 32 into one full wave of 240 tiles and wins in
+    // isolation (109 vs 102 TF, warm caches), but with one workgroup per CU nothing hides its cold-weight prologue
+    // inside the real layer sequence (304-335 us vs 298-310 us for 64x64), so the model does not pick it.
     struct Cand { int id, bm, bn; double eff; };
-    static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.92}, {3, 128, 64, 0.95}, {4, 64, 128, 0.95}, {6, 160, 128, 0.99}};
+    static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.92}, {3, 128, 64, 0.95}, {4, 64, 128, 0.95}};
     int best = 2;
     double best_cost = 1e300;
     for (const Cand &c : cands) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * p.ngroups;
-        if (c.id == 6 && (p.Ktot < 2048 || tiles > 256)) continue;
         const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
         if (cost < best_cost) { best_cost = cost; best = c.id; }
     }
