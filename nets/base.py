@@ -21,51 +21,46 @@ class TrainWrapperBaseClass():
         raise NotImplementedError
 
     def state_dict(self):
-        model_state = {
-            'generator': self.generator.state_dict(),
-            'generator_optim': None,
-            'discriminator': None,
-            'discriminator_optim': None,
-        }
-        return model_state
+        # same four entries as a reference checkpoint; only the generator carries data on the inference path
+        out = dict.fromkeys(('generator', 'generator_optim', 'discriminator', 'discriminator_optim'))
+        out['generator'] = self.generator.state_dict()
+        return out
 
     def parameters(self):
         return self.generator.parameters()
 
     def load_state_dict(self, state_dict):
-        if 'generator' in state_dict:
-            self.generator.load_state_dict(state_dict['generator'])
-        else:
-            self.generator.load_state_dict(state_dict)
+        # a whole checkpoint ({'generator': ..., optimiser entries ...}) or the generator's own state_dict
+        self.generator.load_state_dict(state_dict.get('generator', state_dict))
 
     def infer_on_audio(self, aud_fn, initial_pose=None, norm_stats=None, **kwargs):
         raise NotImplementedError
 
     def init_params(self):
-        # nets/base.py:58-88: body wrappers model 39 body + 90 hand dims (jaw / eyes / global orient excluded)
-        scale = 2 if self.config.Data.pose.convert_to_6d else 1
-        global_orient = round(0 * scale)
-        leye_pose = reye_pose = round(0 * scale)
-        jaw_pose = round(0 * scale)
-        body_pose = round((63 - 24) * scale)
-        left_hand_pose = right_hand_pose = round(45 * scale)
-        expression = 100 if self.expression else 0
+        """Layout of the modelled pose vector (`nets/base.py:58-88` of the reference).
 
-        b_j = 0
-        jaw_dim = jaw_pose
-        b_e = b_j + jaw_dim
-        eye_dim = leye_pose + reye_pose
-        b_b = b_e + eye_dim
-        body_dim = global_orient + body_pose
-        b_h = b_b + body_dim
-        hand_dim = left_hand_pose + right_hand_pose
-        b_f = b_h + hand_dim
-        face_dim = expression
-
-        self.dim_list = [b_j, b_e, b_b, b_h, b_f]
-        self.full_dim = jaw_dim + eye_dim + body_dim + hand_dim
-        self.pose = int(self.full_dim / round(3 * scale))
-        self.each_dim = [jaw_dim, eye_dim + body_dim, hand_dim, face_dim]
+        The body wrappers model no jaw / eye / global-orientation dims (they are fixed or come from the face generator):
+        13 body joints (21 SMPL-X body joints minus the 8 lower-body ones) and 2 x 15 hand joints, 3 values each in
+        axis-angle or 6 in the 6-D rotation form, plus 100 expression coefficients when `expression` is set.
+        Sets `dim_list` (start offsets of jaw, eyes, body, hands, face), `full_dim`, `pose` (joint count) and
+        `each_dim` = [jaw, eyes + body, hands, face] widths.
+        """
+        per_joint = 6 if self.config.Data.pose.convert_to_6d else 3
+        widths = {
+            'jaw': 0,
+            'eyes': 0,
+            'body': (21 - 8) * per_joint,
+            'hands': 2 * 15 * per_joint,
+            'face': 100 if self.expression else 0,
+        }
+        offsets, at = [], 0
+        for part in ('jaw', 'eyes', 'body', 'hands', 'face'):
+            offsets.append(at)
+            at += widths[part]
+        self.dim_list = offsets
+        self.full_dim = widths['jaw'] + widths['eyes'] + widths['body'] + widths['hands']
+        self.pose = self.full_dim // per_joint
+        self.each_dim = [widths['jaw'], widths['eyes'] + widths['body'], widths['hands'], widths['face']]
 
 
 def resolve_device(gpu):
