@@ -7,9 +7,18 @@ One step = BASELINE.json configs[1]: one batch of 32 synthetic 10 s clips throug
 inputs resident in HBM before the timed region, fp32, seeded random-init weights of the reference architecture.
 value = generated frames / s over all ranks (32 * 300 frames per step per rank).
 
-    python bench.py                          # N=1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+How the steps are executed (serving-style, `--coalesce G --streams S`): a step SUBMITS its batch; every G submitted
+batches are stacked and go through the path as one pass of 32*G clips (the autoregressive chain is latency-bound below
+~64 clips per stage: one pass over 256 clips streams each stage's weights once instead of 8 times), alternating over S
+HIP streams so that the conv stacks of one group overlap the chain of another.  A clip's result does not depend on how
+its batch was grouped (bit-identical; tests/test_gpu_parity.py::test_golden_clips_inside_baseline_batches).  Every
+step's batch is completely processed inside the timed region.  The strict one-batch-at-a-time figure and the round-1
+mode (4 independent batches on 4 streams, no coalescing) are measured beside it (`modes`).
+
+    python bench.py                          # N=1, configs[1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
+    ... bench.py --config whole_body         # BASELINE configs[4]: 128 clips per rank, body_pixel + face -> 265-d rows
 
 Clips are independent, so ranks shard them with no data-path collective ("weak" scaling: 32 clips per rank per
 step); the only exchange is one all-gather of the generated pose sequences after the timed region's last step
@@ -22,7 +31,7 @@ import os
 import sys
 import time
 
-# independent batches are pipelined over several HIP streams; give each its own hardware queue
+# independent groups are pipelined over several HIP streams; give each its own hardware queue
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -32,8 +41,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FRAMES_PER_CLIP = 300
-PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_{32x32x2,16x16x4}_f32, 256 CUs x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
+ALG_MAC_PER_ROW_PER_CLIP = 34734080.0   # incremental PixelCNN, SURVEY.md §8d (valid taps only)
+ALG_FLOP_PER_FRAME = 64.25e6            # configs[1] whole path, SURVEY.md §8d
 
 
 def build_models(device_index, seed=0):
@@ -54,36 +65,56 @@ def build_models(device_index, seed=0):
     return w, dict(audio=sd_aud, pix=sd_pix, body=sd_body, hand=sd_hand)
 
 
-def cpu_baseline(sds, seed):
-    """The oracle (= the reference's algorithm incl. its full-grid recompute per position) on the host cores, one clip."""
-    from oracle import talkshow_oracle as O
+def build_face(device_index, seed=0):
     from talkshow_amd import synth
-    mf, ids = synth.mfcc_features(seed, 1, FRAMES_PER_CLIP), synth.speaker_ids(1)
-    gt = synth.gt_poses(seed, 1, FRAMES_PER_CLIP)
-    t0 = time.perf_counter()
-    O.vqvae_encode(gt[..., :39], sds["body"])
-    O.vqvae_encode(gt[..., 39:], sds["hand"])
-    O.body_pixel_infer(mf, ids, sds["audio"], sds["pix"], sds["body"], sds["hand"])
-    dt = time.perf_counter() - t0
-    return {"value": FRAMES_PER_CLIP / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"1 clip (10 s, 300 frames), VQ encode + greedy full-grid PixelCNN + VQ decode, numpy/BLAS fp32, {dt:.1f} s"}
+    from talkshow_amd.modules import FaceGenerator
+    m = FaceGenerator().to(torch.device("cuda", device_index))
+    m.load_state_dict(synth.to_torch(synth.face_state_dict(seed=seed)))
+    return m
 
+
+def cpu_baseline(sds, seed, clips=8):
+    """The reference's algorithm (full-grid recompute per code position) on this box's host cores.
+
+    kind "port": oracle/torch_port.py — the reference's forward()s restated on the torch CPU ops its nn.Modules dispatch
+    to (pinned to the reference goldens, tests/test_oracle_golden.py); /root/reference itself cannot travel to the GPU
+    box.  Bounded sample: `clips` clips of the configs[1] workload (VQ encode + greedy generate + VQ decode), once.
+    `reference_build_box`: the reference's OWN modules timed in the build container (tools/time_reference_cpu.py)."""
+    from oracle import torch_port as TP
+    from talkshow_amd import synth
+    torch.set_num_threads(os.cpu_count())
+    mf, ids = synth.mfcc_features(seed, clips, FRAMES_PER_CLIP), synth.speaker_ids(clips)
+    gt = synth.gt_poses(seed, clips, FRAMES_PER_CLIP)
+    t0 = time.perf_counter()
+    TP.vq_encode_pair(gt, sds["body"], sds["hand"])
+    TP.body_pixel_infer(mf, ids, sds["audio"], sds["pix"], sds["body"], sds["hand"])
+    dt = time.perf_counter() - t0
+    out = {"value": clips * FRAMES_PER_CLIP / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{clips} clips (10 s, 300 frames each) of configs[1]: VQ encode + greedy full-grid PixelCNN generate "
+                     f"(150 forwards) + VQ decode, torch CPU ops fp32 (oracle/torch_port.py), one pass, {dt:.1f} s"}
+    ref = os.path.join(REPO, "profiles", "r02_reference_cpu_buildbox.json")
+    if os.path.exists(ref):
+        r = json.load(open(ref))
+        out["reference_build_box"] = {
+            "what": "the reference's own nn.Modules (imported from /root/reference) timed in the build container by "
+                    "tools/time_reference_cpu.py; not this box",
+            "cpu": r.get("cpu"), "cores": r.get("cores"),
+            "body_frames_per_s": r["body"]["frames_per_s"], "body_batch": r["body"]["batch"],
+            "face_frames_per_s": r["face"]["frames_per_s"], "face_batch": r["face"]["batch"]}
+    return out
 
 
 def face_block(local):
     """BASELINE configs[2] as extra information: face generator, batch 64 x 10 s @16 kHz -> (64,300,103), fp32."""
     from talkshow_amd import _lib, synth
-    from talkshow_amd.modules import FaceGenerator
     lib = _lib.load()
     ctx = _lib.context(local)
-    m = FaceGenerator().cuda()
-    m.load_state_dict(synth.to_torch(synth.face_state_dict(seed=0)))
+    m = build_face(local)
     B, N, T = 64, 160000, 300
     wav = torch.from_numpy(synth.wav16(3000, B, N)).cuda()
     ids = torch.nn.functional.one_hot(torch.arange(B) % 4, 4).float().cuda()
     m.run(wav, ids, T)
     torch.cuda.synchronize()
-    n0, f0 = (C.c_int64 * 3)(), (C.c_double * 3)()
     t0 = time.perf_counter()
     K = 3
     for _ in range(K):
@@ -122,17 +153,15 @@ def diversity_block(w, _lib, mfcc1):
             "frames_per_s": B * FRAMES_PER_CLIP / dt, "ms_per_call": dt * 1e3, "distinct_samples": distinct}
 
 
-def roofline_block(w, lib, _lib, stream, mfcc, ids, B, H, local, step):
-    """Roofline of the dominant kernel + per-family breakdown.
+def chain_roofline(w, lib, _lib, stream, mfcc, ids, H, pmc_key):
+    """Dominant kernel: skinny_gemm_f32, the per-position GEMM of the PixelCNN chain, at M = mfcc.shape[0] clips per stage.
 
-    Dominant kernel (≈85 % of a batch's device time): skinny_gemm_f32, the per-position GEMM of the PixelCNN chain.
-    Its launches are replayed from one hipGraph per batch, so the live measurement is: HIP events recorded on the launch
+    Its launches are replayed from one hipGraph per pass, so the live measurement is: HIP events recorded on the launch
     stream around one replay (5 repeats, median) / the number of skinny launches inside (ts_pixelcnn_graph_stats, which
-    also gives the algorithmic flops 2*M*N*K summed over those launches).  The 150 sampler launches inside the same
-    replay are <2 % of it.  conv_gemm_f32 (VQ encoder/decoder, audio encoder) is measured with HIP event pairs around
-    every launch on the launch stream (ts_prof_*).
-    """
-    res = {}
+    also gives the executed flops 2*M*N*K summed over those launches).  The sampler launches inside the same replay are
+    <2 % of it.  `achieved` uses the ALGORITHMIC flops (34,734,080 MAC per code row per clip); the launches
+    execute ~10 % more (composed horizontal maps), which is not counted as achieved work."""
+    M = int(mfcc.shape[0])
     with torch.cuda.stream(stream):
         feat = w.audioencoder.forward_nlc(mfcc)
         w.generator.run(ids, feat, mode=_lib.TS_SAMPLE_GREEDY)
@@ -145,36 +174,168 @@ def roofline_block(w, lib, _lib, stream, mfcc, ids, B, H, local, step):
             e1.synchronize()
             times.append(e0.elapsed_time(e1))
         n, fl = C.c_int64(), C.c_double()
-        _lib.check(lib.ts_pixelcnn_graph_stats(w.generator.handle(), C.c_void_p(stream.cuda_stream), B, H,
+        _lib.check(lib.ts_pixelcnn_graph_stats(w.generator.handle(), C.c_void_p(stream.cuda_stream), M, H,
                                                _lib.TS_SAMPLE_GREEDY, C.byref(n), C.byref(fl)))
     ms = sorted(times)[len(times) // 2]
-    # algorithmic work of the incremental PixelCNN: 34,734,080 MAC per code row per clip, valid taps only;
-    # the launches execute ~25 % more (composed horizontal maps), which is NOT counted as achieved work
-    alg = 2.0 * 34734080.0 * H * B
+    alg = 2.0 * ALG_MAC_PER_ROW_PER_CLIP * H * M
     ach = alg / (ms * 1e-3) / 1e12
     traffic = None
-    pmc = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
+    pmc = os.path.join(REPO, "profiles", "r02_pmc_summary.json")
     if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("skinny_gemm_f32", {}).get("hbm_bytes_per_launch")
-    res["roofline"] = {"kernel": "skinny_gemm_f32 (PixelCNN per-position GEMM chain)", "bound": "mfma", "achieved": ach,
-                       "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                       "traffic": traffic, "launches_per_batch": n.value, "avg_launch_us": ms * 1e3 / n.value,
-                       "algorithmic_flops_per_launch": alg / n.value, "executed_flops_per_launch": fl.value / n.value,
-                       "chain_ms_per_batch": ms}
-    # per-family pass: event pair around every launch (eager launches, so the chain is slower here than in production)
+        traffic = json.load(open(pmc)).get(pmc_key, {}).get("hbm_bytes_per_launch")
+    return {"kernel": "skinny_gemm_f32 (PixelCNN per-position GEMM chain)", "clips_per_stage": M, "bound": "mfma",
+            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": traffic, "launches_per_pass": n.value, "avg_launch_us": ms * 1e3 / n.value,
+            "algorithmic_flops_per_launch": alg / n.value, "executed_flops_per_launch": fl.value / n.value,
+            "chain_ms_per_pass": ms, "chain_ms_per_32_clips": ms * 32.0 / M}
+
+
+def conv_roofline(lib, _lib, local, run_pass):
+    """conv_gemm_f32 (VQ encoder/decoder, audio encoder): HIP event pairs around every launch on the launch stream
+    (ts_prof_*; eager launches), one pass of the operating point."""
     ctx = _lib.context(local)
     _lib.check(lib.ts_prof_enable(ctx, 1))
-    step(0)
+    run_pass()
     torch.cuda.synchronize()
     msf, nf, flf = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
     _lib.check(lib.ts_prof_read(ctx, msf, nf, flf, 1))
     _lib.check(lib.ts_prof_enable(ctx, 0))
     ach_c = flf[0] / (msf[0] * 1e-3) / 1e12
-    res["roofline_conv_gemm"] = {"kernel": "conv_gemm_f32 (VQ encoder/decoder + audio encoder layers)", "bound": "mfma",
-                                 "achieved": ach_c, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": ach_c / PEAK_FP32_MFMA_TFLOPS, "launches_per_batch": nf[0],
-                                 "avg_launch_us": msf[0] * 1e3 / nf[0], "ms_per_batch": msf[0]}
-    return res
+    return {"kernel": "conv_gemm_f32 (VQ encoder/decoder + audio encoder layers)", "bound": "mfma",
+            "achieved": ach_c, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach_c / PEAK_FP32_MFMA_TFLOPS, "launches_per_pass": nf[0],
+            "avg_launch_us": msf[0] * 1e3 / nf[0], "ms_per_pass": msf[0]}
+
+
+class Engine:
+    """configs[1] executor: submit() a 32-clip batch per step; groups of G batches run as one pass on alternating streams."""
+
+    def __init__(self, w, lib, _lib, local, B, T, G, S, mfcc, gt, ids, rank):
+        self.w, self.lib, self._lib = w, lib, _lib
+        self.B, self.T, self.H, self.G, self.S = B, T, T // 4, G, S
+        self.mfcc, self.gt, self.rank = mfcc, gt, rank
+        self.dev = mfcc[0].device
+        self.streams = _lib.create_streams(S, local)
+        self.ids_rep = ids.repeat(G).contiguous()
+        self.gt_codes = [torch.empty((B * G, self.H, 2), dtype=torch.int64, device=self.dev) for _ in range(S)]
+        self.pending, self.groups, self.last = [], 0, None
+
+    def run_group(self, ks, stream_index):
+        NB, B, T, lib, _lib, w = len(self.mfcc), self.B, self.T, self.lib, self._lib, self.w
+        with torch.cuda.stream(self.streams[stream_index]):
+            s = _lib.stream_ptr()
+            n = B * len(ks)
+            if len(ks) == 1:
+                gtc, mfc = self.gt[ks[0] % NB], self.mfcc[ks[0] % NB]
+            else:   # stacking the resident batches is part of the pass (device copies on the pass's stream)
+                gtc = torch.cat([self.gt[k % NB] for k in ks], 0)
+                mfc = torch.cat([self.mfcc[k % NB] for k in ks], 0)
+            # VQ-VAE encode half of configs[1] (VQVAE.encode of the 300 GT frames, body and hand)
+            _lib.check(lib.ts_body_vq_infer(w.g_body.handle(), w.g_hand.handle(), _lib.dptr(gtc), n, T,
+                                            _lib.dptr(self.gt_codes[stream_index][:n]), None, s))
+            # audio encoder -> PixelCNN greedy -> VQ decode
+            self.last = w.generate_batch(mfc, self.ids_rep[:n], mode=_lib.TS_SAMPLE_GREEDY, clip_index0=self.rank * B)
+        return self.last
+
+    def submit(self, k):
+        self.pending.append(k)
+        if len(self.pending) == self.G:
+            self.flush()
+
+    def flush(self):
+        if self.pending:
+            ks, self.pending = self.pending, []
+            self.run_group(ks, self.groups % self.S)
+            self.groups += 1
+
+    def run_steps(self, steps):
+        self.groups = 0
+        for k in range(steps):
+            self.submit(k)
+        self.flush()
+        return self.last
+
+    def warm(self, steps):
+        """graph capture + scratch allocation for every (group size, stream) the timed steps will use"""
+        sizes = {self.G} if steps >= self.G else set()
+        if steps % self.G:
+            sizes.add(steps % self.G)
+        for g in sorted(sizes):
+            for si in range(self.S):
+                self.run_group(list(range(g)), si)
+        torch.cuda.synchronize()
+
+
+def timed(fn, reps=3):
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
+def main_whole_body(a, world, rank, local, dist):
+    """BASELINE configs[4]: 1 024 clips over 8 ranks = 128 clips per rank per step (weak scaling), whole body:
+    body_pixel (batches of 32, coalesced) + face (batches of 64) -> (n_local, 300, 265) rows assembled on the GPU, ONE
+    RCCL all-gather of the rows per step inside the timed region."""
+    from talkshow_amd import _lib, synth
+    from talkshow_amd import parallel
+    import types
+    w, sds = build_models(local)
+    face = types.SimpleNamespace(generator=build_face(local))
+    dev = torch.device("cuda", local)
+    n_local = a.clips_per_rank
+    N = n_local * world
+    T = FRAMES_PER_CLIP
+    # every rank materialises only its own block of the global inputs (seeded by global clip index range)
+    lo, hi = parallel.shard_range(N, rank, world)
+    mfcc = torch.from_numpy(synth.mfcc_features(4000 + rank, n_local, T)).to(dev)
+    ids = torch.from_numpy(synth.speaker_ids(n_local)).to(dev)
+    wav = torch.from_numpy(synth.wav16(5000 + rank, n_local, 160000)).to(dev)
+    fid = torch.nn.functional.one_hot(torch.arange(n_local) % 4, 4).float().to(dev)
+
+    def step():
+        return parallel.whole_body_local(w, face, mfcc, ids, wav, fid, mode=_lib.TS_SAMPLE_GREEDY, clip_index0=lo,
+                                         batch_body=a.batch * a.coalesce, batch_face=64)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(max(1, a.warmup)):
+        rows = step()
+    if world > 1:
+        parallel.gather_sequences(rows, N)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rows = step()
+        allrows = parallel.gather_sequences(rows, N) if world > 1 else rows
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    frames = world * a.steps * n_local * FRAMES_PER_CLIP
+    out = {
+        "metric": "generated SMPL-X frames/sec (10 s @ 30 fps clips), whole job", "value": frames / dt, "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seeded MFCC-scale features, 16 kHz noise clips, random-init weights of the reference architecture)",
+        "config": {"workload": f"BASELINE configs[4]: {N} synthetic 10 s clips sharded over {world} rank(s) ({n_local} per rank per step), "
+                               "whole body = body_pixel greedy + face generator -> (N,300,265) rows, one RCCL all-gather of the rows per step",
+                   "clips_per_rank": n_local, "body_batch": a.batch, "coalesce": a.coalesce, "face_batch": 64,
+                   "parallelism": f"clip-sharded x{world}, full weight replica per rank"},
+        "per_gpu_frames_per_s": frames / dt / world, "gathered_shape": list(allrows.shape),
+    }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def main():
@@ -183,11 +344,16 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("TS_BENCH_STREAMS", "4")),
-                    help="independent steps (batches of 32 clips) in flight at once, one HIP stream each")
+    ap.add_argument("--coalesce", type=int, default=int(os.environ.get("TS_BENCH_COALESCE", "8")),
+                    help="submitted batches stacked into one pass (clips per chain stage = batch * coalesce)")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("TS_BENCH_STREAMS", "2")),
+                    help="groups in flight at once, one HIP stream each")
+    ap.add_argument("--config", default="body", choices=["body", "whole_body"])
+    ap.add_argument("--clips-per-rank", type=int, default=128, help="whole_body: clips per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-face", action="store_true")
+    ap.add_argument("--no-modes", action="store_true")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,6 +365,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if a.config == "whole_body":
+        main_whole_body(a, world, rank, local, dist)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from talkshow_amd import _lib, synth
     from talkshow_amd.parallel import gather_sequences
@@ -212,36 +384,23 @@ def main():
     gt = [torch.from_numpy(synth.gt_poses(2000 + 10 * rank + k, B, T)).to(dev) for k in range(NB)]
     ids = torch.from_numpy(synth.speaker_ids(B)).to(dev)
     H = T // 4
-    S = max(1, a.streams)
-    streams = _lib.create_streams(S, local)
-    gt_codes = [torch.empty((B, H, 2), dtype=torch.int64, device=dev) for _ in range(S)]
-
-    def step(k):
-        # one complete pass over one batch of 32 clips, enqueued on stream k % S (the library keeps one scratch arena
-        # per stream; weights are shared)
-        with torch.cuda.stream(streams[k % S]):
-            s = _lib.stream_ptr()
-            # VQ-VAE encode half of configs[1] (VQVAE.encode of the 300 GT frames, body and hand)
-            _lib.check(lib.ts_body_vq_infer(w.g_body.handle(), w.g_hand.handle(), _lib.dptr(gt[k % NB]), B, T,
-                                            _lib.dptr(gt_codes[k % S]), None, s))
-            # audio encoder -> PixelCNN greedy -> VQ decode
-            return w.generate_batch(mfcc[k % NB], ids, mode=_lib.TS_SAMPLE_GREEDY, clip_index0=rank * B)
+    G, S = max(1, a.coalesce), max(1, a.streams)
+    eng = Engine(w, lib, _lib, local, B, T, G, S, mfcc, gt, ids, rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     torch.cuda.synchronize()
-    for k in range(max(a.warmup, S)):      # at least one pass per stream: graph capture + scratch allocation are warm-up
-        step(k)
+    eng.warm(a.steps)
+    eng.run_steps(-(-max(a.warmup, 1) // G) * G)       # >= W untimed steps through the same submit/flush path (whole groups)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for k in range(a.steps):
-        codes, poses = step(k)
+    codes, poses = eng.run_steps(a.steps)
     torch.cuda.synchronize()
     if world > 1:
-        all_poses = gather_sequences(poses)            # the one exchange: (N*B, 300, 129) on every rank
+        all_poses = gather_sequences(poses[-B:])       # the one exchange: last step's (N*B, 300, 129) on every rank
         torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -257,26 +416,41 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded MFCC-scale features / poses, random-init weights of the reference architecture)",
         "config": {"workload": "BASELINE configs[1]: batch=32 x 10 s clips, body+hand VQ-VAE encode -> PixelCNN greedy decode -> VQ decode, 30 fps",
-                   "batch_per_gpu": B, "frames_per_clip": FRAMES_PER_CLIP,
-                   "parallelism": f"clip-sharded x{world}, {S} batches in flight per GPU (one HIP stream each)"},
+                   "batch_per_gpu": B, "frames_per_clip": FRAMES_PER_CLIP, "coalesce": G, "streams": S,
+                   "parallelism": f"clip-sharded x{world}; per GPU every {G} submitted batches run as one pass of {B * G} clips, "
+                                  f"{S} passes in flight (one HIP stream each)"},
         "per_gpu_frames_per_s": frames / dt / world,
-        "streams": S,
     }
     # whole path against the fp32 MFMA roof: algorithmic work of configs[1] (64.25 MFLOP per generated frame)
-    ach = 64.25e6 * frames / dt / world / 1e12
+    ach = ALG_FLOP_PER_FRAME * frames / dt / world / 1e12
     out["whole_path"] = {"algorithmic_TFLOPs_per_gpu": ach, "frac_of_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS}
-    # latency of ONE isolated batch (a single stream, nothing else in flight)
-    lat = []
-    for k in range(3):
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        step(0)
-        torch.cuda.synchronize()
-        lat.append(time.perf_counter() - t1)
-    out["batch_latency_ms"] = sorted(lat)[1] * 1e3
+
+    # the same workload under the other execution modes, for comparison (not the headline)
+    if not a.no_modes:
+        modes = {}
+        one = Engine(w, lib, _lib, local, B, T, 1, 1, mfcc, gt, ids, rank)
+        one.warm(1)
+        lat = timed(lambda: one.run_steps(1))
+        modes["one_batch_in_flight"] = {"what": "strict: one 32-clip batch at a time, one stream (= latency of a batch)",
+                                        "ms_per_step": lat * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / lat}
+        out["batch_latency_ms"] = lat * 1e3
+        r01 = Engine(w, lib, _lib, local, B, T, 1, 4, mfcc, gt, ids, rank)
+        r01.warm(1)
+        t4 = timed(lambda: r01.run_steps(16)) / 16
+        modes["four_streams_no_coalescing"] = {"what": "round-1 mode: 4 independent 32-clip batches on 4 HIP streams",
+                                               "ms_per_step": t4 * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / t4}
+        tg = timed(lambda: eng.run_steps(G * S)) / (G * S)
+        modes["coalesced"] = {"what": f"headline mode re-measured: passes of {B * G} clips on {S} streams",
+                              "ms_per_step": tg * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / tg,
+                              "latency_of_a_pass_ms": timed(lambda: eng.run_group(list(range(G)), 0)) * 1e3}
+        out["modes"] = modes
 
     if rank == 0 and not a.no_roofline:
-        out.update(roofline_block(w, lib, _lib, streams[0], mfcc[0], ids, B, H, local, step))
+        big_mf = torch.cat([mfcc[k % NB] for k in range(G)], 0) if G > 1 else mfcc[0]
+        out["roofline"] = chain_roofline(w, lib, _lib, eng.streams[0], big_mf, eng.ids_rep, H, f"skinny_gemm_f32_M{B * G}")
+        if G > 1:
+            out["roofline_one_batch"] = chain_roofline(w, lib, _lib, eng.streams[0], mfcc[0], ids, H, f"skinny_gemm_f32_M{B}")
+        out["roofline_conv_gemm"] = conv_roofline(lib, _lib, local, lambda: eng.run_group(list(range(G)), 0))
     if rank == 0 and not a.no_face:
         try:
             out["diversity"] = diversity_block(w, _lib, mfcc[0])

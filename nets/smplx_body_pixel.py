@@ -9,7 +9,7 @@ import torch
 from nets.base import TrainWrapperBaseClass, resolve_device
 from talkshow_amd import _lib
 from talkshow_amd.frontend import get_mfcc_sepa, get_mfcc_ta
-from talkshow_amd.modules import AudioEncoder, GatedPixelCNN as pixelcnn, VQVAE as s2g_body
+from talkshow_amd.modules import AudioEncoder, GatedPixelCNN as pixelcnn, VQVAE as s2g_body, _check_index_range
 from talkshow_amd.pose_index import c_index_3d
 
 
@@ -115,6 +115,12 @@ class TrainWrapper(TrainWrapperBaseClass):
         ids = torch.as_tensor(ids, dtype=torch.int64, device=dev).reshape(-1).contiguous()
         B, T, _ = mfcc.shape
         H = T // 2 // 2
+        # nn.Embedding of a single label broadcasts over the batch in the reference (gated_pixelcnn_v2.py:65-66)
+        if ids.numel() == 1 and B > 1:
+            ids = ids.repeat(B)
+        if ids.numel() != B:
+            raise ValueError(f"ids must hold 1 or B={B} speaker indices, got {ids.numel()}")
+        _check_index_range(ids, self.num_classes, 'speaker id')   # IndexError like nn.Embedding; sync-free once seen
         codes = torch.zeros((B, H, 2), dtype=torch.int64, device=dev)
         poses = torch.empty((B, 4 * H, self.each_dim[1] + self.each_dim[2]), dtype=torch.float32, device=dev)
         if uniforms is not None:
@@ -124,6 +130,23 @@ class TrainWrapper(TrainWrapperBaseClass):
             _lib.dptr(mfcc), _lib.dptr(ids), B, T, mode, _lib.dptr(uniforms), int(seed) & (2 ** 64 - 1), int(clip_index0),
             _lib.dptr(codes), _lib.dptr(poses), _lib.stream_ptr()))
         return codes, poses
+
+    def generate_batches(self, mfccs, ids_list, mode=_lib.TS_SAMPLE_PHILOX, seed=0, clip_index0=0):
+        """Coalesced execution of several independent batches (the serving path): the batches' clips are stacked and
+        the autoregressive chain runs ONCE over all of them, so a stage's weights are streamed once for all batches
+        in flight instead of once per batch (a chain stage is latency-bound below ~64 clips).  Results are bit-identical
+        to running each batch alone (tests/test_gpu_parity.py::test_golden_clips_inside_baseline_batches); global clip
+        indices (the Philox subsequences) run on from `clip_index0` in list order.
+
+        mfccs: list of (B_i,T,64) device tensors, ids_list: list of (B_i,) -> list of (codes_i, poses_i) views."""
+        dev = self.generator._dev()
+        sizes = [int(m.shape[0]) for m in mfccs]
+        mf = torch.cat([torch.as_tensor(m, dtype=torch.float32, device=dev) for m in mfccs], 0)
+        ids = torch.cat([torch.as_tensor(i, dtype=torch.int64, device=dev).reshape(-1).expand(b) if
+                         torch.as_tensor(i).numel() == 1 else torch.as_tensor(i, dtype=torch.int64, device=dev).reshape(-1)
+                         for i, b in zip(ids_list, sizes)], 0)
+        codes, poses = self.generate_batch(mf, ids, mode=mode, seed=seed, clip_index0=clip_index0)
+        return list(zip(codes.split(sizes, 0), poses.split(sizes, 0)))
 
     def infer_on_audio(self, aud_fn, initial_pose=None, norm_stats=None, exp=None, var=None, w_pre=False, rand=None,
                        continuity=False, id=None, fps=15, sr=22000, B=1, am=None, am_sr=None, frame=0, **kwargs):
@@ -149,6 +172,9 @@ class TrainWrapper(TrainWrapperBaseClass):
         if id is None:
             id = torch.tensor([0]).to(self.device)
         else:
+            lo, hi = int(id.min()), int(id.max())                 # nn.Embedding's IndexError, before anything is launched
+            if lo < 0 or hi >= self.num_classes:
+                raise IndexError(f"speaker id out of range: [{lo}, {hi}] not within [0, {self.num_classes})")
             id = id.repeat(B)
 
         mode = _lib.TS_SAMPLE_GREEDY if kwargs.get('greedy', False) else _lib.TS_SAMPLE_PHILOX

@@ -253,19 +253,26 @@ def softmax(x):
     return (e / e.sum(axis=-1, keepdims=True)).astype(F32)
 
 
-def pixelcnn_generate(label, aud, sd, n_layers, H, uniforms=None, return_logits=False):
+def pixelcnn_generate(label, aud, sd, n_layers, H, uniforms=None, return_logits=False, pre_latents=None, pre_audio=None):
     """GatedPixelCNN.generate (`gated_pixelcnn_v2.py:152-177`) — the O(H^2) full-grid recompute, as written.
 
     `uniforms is None`: greedy harness of SURVEY.md §0.3 (argmax of logits[:, :, i, j], ties -> lowest
     index).  Otherwise `uniforms` (B,H,2) in [0,1) drives an inverse-CDF draw from
     softmax(logits[:, :, i, j]) — the distribution `probs.multinomial(1)` samples (`:173-176`); torch's
     RNG stream itself is not reproducible off-torch, so stochastic parity is defined on injected uniforms.
+    `pre_latents` (B,H0,2) / `pre_audio` (B,256,H0,2): the continuity prefix (`:158-165`) — known codes and their
+    audio rows are prepended, positions h0..h0+H-1 are generated, and only those are returned.
     """
     sd = causal_weights(sd, n_layers)
     B = aud.shape[0]
     x = np.zeros((B, H, 2), np.int64)
+    h0 = 0
+    if pre_latents is not None:
+        x = np.concatenate([np.asarray(pre_latents, np.int64), x], axis=1)
+        aud = np.concatenate([pre_audio, aud], axis=2)
+        h0 = pre_latents.shape[1]
     logs = []
-    for i in range(H):
+    for i in range(h0, h0 + H):
         for j in range(2):
             lg = pixelcnn_forward(x, label, aud, sd, n_layers)[:, :, i, j]
             if return_logits:
@@ -273,7 +280,8 @@ def pixelcnn_generate(label, aud, sd, n_layers, H, uniforms=None, return_logits=
             if uniforms is None:
                 x[:, i, j] = np.argmax(lg, axis=-1)
             else:
-                x[:, i, j] = sample_inverse_cdf(lg, uniforms[:, i, j])
+                x[:, i, j] = sample_inverse_cdf(lg, uniforms[:, i - h0, j])
+    x = x[:, h0:]
     if return_logits:
         return x, np.stack(logs, 1).reshape(B, H, 2, -1)
     return x
@@ -360,6 +368,22 @@ def body_pixel_infer(mfcc, ids, sd_audio, sd_pix, sd_body, sd_hand, n_layers=15,
     hand = vqvae_decode(codes[..., 1], sd_hand)
     poses = np.concatenate([body, hand], axis=1).transpose(0, 2, 1)
     return codes, np.ascontiguousarray(poses), feat
+
+
+def body_pixel_infer_continuity(mfcc, gap, ids, sd_audio, sd_pix, sd_body, sd_hand, n_layers=15):
+    """`infer_on_audio(continuity=True)` (`smplx_body_pixel.py:260-269,291-304`), greedy: the features are split at frame
+    `gap` (`get_mfcc_sepa`), each part goes through the audio encoder and the decoders on its own, and the second part's
+    codes are generated behind the first part's codes and audio rows as prefix.  -> poses (B, 4*(H0+H1), 129), codes."""
+    def part(m, pre_codes=None, pre_aud=None):
+        feat = audio_encoder(np.ascontiguousarray(m.transpose(0, 2, 1)), sd_audio)
+        aud = np.repeat(feat[:, :, :, None], 2, axis=3)
+        codes = pixelcnn_generate(ids, aud, sd_pix, n_layers, aud.shape[2], pre_latents=pre_codes, pre_audio=pre_aud)
+        body, hand = vqvae_decode(codes[..., 0], sd_body), vqvae_decode(codes[..., 1], sd_hand)    # Decoder ignores pre_state
+        return codes, aud, body, hand
+    c0, a0, b0, h0 = part(mfcc[:, :gap])
+    c1, _, b1, h1 = part(mfcc[:, gap:], c0, a0)
+    poses = np.concatenate([np.concatenate([b0, b1], 2), np.concatenate([h0, h1], 2)], axis=1).transpose(0, 2, 1)
+    return np.ascontiguousarray(poses), np.concatenate([c0, c1], 1)
 
 
 def assemble_full(body, face, lower_pose33):

@@ -11,10 +11,8 @@ struct BodyWork {
 };
 // scratch between the stages of ts_body_pixel_infer (audio feature map, split latents), one set per stream
 BodyWork &body_work(hipStream_t s) {
-    static thread_local std::map<hipStream_t, std::unique_ptr<BodyWork>> m;
-    auto &w = m[s];
-    if (!w) w.reset(new BodyWork());
-    return *w;
+    static StreamWorks<BodyWork> works;
+    return works.get(s);
 }
 }  // namespace
 
@@ -64,6 +62,8 @@ int ts_debug_skinny_trace(unsigned long long *out, int max_records) {
 }
 int ts_stream_destroy(ts_ctx *ctx, void *stream) {
     if (!ctx) return fail("ts_stream_destroy: null ctx");
+    TS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    drop_stream_everywhere((hipStream_t)stream);   // scratch arenas and captured graphs keyed by this handle
     TS_HIP(hipStreamDestroy((hipStream_t)stream));
     return 0;
 }

@@ -95,12 +95,8 @@ struct ts_face {
     struct Work {
         DevBuf A, Bf, part, stats, X512, H, H2, TMP, QKV, SC, VT, ATT, FF, X320, Y1, Y2, R, D1, D2;
     };
-    std::map<hipStream_t, std::unique_ptr<Work>> works;
-    Work &work(hipStream_t s) {
-        auto &w = works[s];
-        if (!w) w.reset(new Work());
-        return *w;
-    }
+    StreamWorks<Work> works;
+    Work &work(hipStream_t s) { return works.get(s); }
 };
 
 namespace ts {

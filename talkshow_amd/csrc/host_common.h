@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -61,6 +63,50 @@ struct DevBuf {
 };
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- per-stream scratch --------------------------------------------------------------------------------------
+// Every model object keeps one Work (activation arena, captured graphs) per HIP stream, created on the stream's first
+// call, so independent batches can be in flight on different streams against one weight copy.  Lookups are serialised:
+// two host threads may make their first call on two new streams at the same time.  A Work itself is only ever touched
+// by the thread driving its stream (contract in talkshow_hip.h: one host thread per stream at a time).
+// ts_stream_destroy() evicts the Work of the dying stream from every live object (a later stream could reuse the handle
+// value and would otherwise inherit graphs captured for the old one).
+struct StreamScoped {
+    StreamScoped();
+    virtual ~StreamScoped();
+    virtual void drop_stream(hipStream_t s) = 0;
+    StreamScoped(const StreamScoped &) = delete;
+    StreamScoped &operator=(const StreamScoped &) = delete;
+};
+void drop_stream_everywhere(hipStream_t s);
+
+template <class W>
+struct StreamWorks : StreamScoped {
+    std::mutex mu;
+    std::map<hipStream_t, std::unique_ptr<W>> m;
+    W &get(hipStream_t s) {
+        std::lock_guard<std::mutex> g(mu);
+        auto &w = m[s];
+        if (!w) w.reset(new W());
+        return *w;
+    }
+    W *find(hipStream_t s) {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = m.find(s);
+        return it == m.end() ? nullptr : it->second.get();
+    }
+    void drop_stream(hipStream_t s) override {
+        std::lock_guard<std::mutex> g(mu);
+        m.erase(s);
+    }
+};
+
+// relaxed atomic accumulate for the always-on diagnostic counters (several host threads may launch concurrently)
+inline void atomic_add(std::atomic<double> &a, double v) {
+    double cur = a.load(std::memory_order_relaxed);
+    while (!a.compare_exchange_weak(cur, cur + v, std::memory_order_relaxed)) {
+    }
+}
 
 // view of a reference state_dict, "module." prefixes stripped (nets/smplx_body_pixel.py:119-126)
 struct StateDict {
@@ -128,8 +174,8 @@ struct ts_ctx {
     int device = 0;
     ts::Profiler prof;
     // always-on launch / algorithmic-flop counters per kernel family (cheap host-side bookkeeping)
-    long n_launch[ts::FAM_COUNT] = {0, 0, 0};
-    double n_flops[ts::FAM_COUNT] = {0, 0, 0};
+    std::atomic<long> n_launch[ts::FAM_COUNT] = {};
+    std::atomic<double> n_flops[ts::FAM_COUNT] = {};
     ts::DevBuf neg1;   // a single int32 -1 (gather index meaning "zero row")
 };
 

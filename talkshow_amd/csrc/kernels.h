@@ -124,9 +124,9 @@ hipError_t launch_vq_argmin(const float *x, int ldx, int M, const float *codeboo
                             int dim, int64_t *idx, long idx_stride, hipStream_t stream);
 // code_sq[j] = sum_c e[j][c]^2
 hipError_t launch_row_sqnorm(const float *e, int n, int dim, float *out, hipStream_t stream);
-// out[m][0..width) = table[idx[m*idx_stride]][0..width)
-hipError_t launch_gather_rows(const float *table, int ld_table, const int64_t *idx, long idx_stride, int M, int width,
-                              float *out, int ldo, hipStream_t stream);
+// out[m][0..width) = table[idx[m*idx_stride]][0..width); an index outside [0, nrows) gives a row of NaNs
+hipError_t launch_gather_rows(const float *table, int ld_table, int nrows, const int64_t *idx, long idx_stride, int M,
+                              int width, float *out, int ldo, hipStream_t stream);
 // dst[m][0..cpad) = src[m][0..c) then zeros
 hipError_t launch_pad_rows(const float *src, int lds, int c, float *dst, int ldd, int cpad, long M, hipStream_t stream);
 // (B,Tb,129) body/hand poses + (B,Tf,103) jaw/expression -> (B,Tf,265) full SMPL-X parameter rows (demo.py:207-229, part2full)

@@ -30,12 +30,8 @@ struct ts_mfcc {
     struct Work {
         DevBuf x22, frames, spec, power, melb;
     };
-    std::map<hipStream_t, std::unique_ptr<Work>> works;
-    Work &work(hipStream_t s) {
-        auto &w = works[s];
-        if (!w) w.reset(new Work());
-        return *w;
-    }
+    StreamWorks<Work> works;
+    Work &work(hipStream_t s) { return works.get(s); }
     long resampled_len(long N) const { return (nnew * N + norig - 1) / norig; }
 };
 

@@ -15,6 +15,36 @@ static thread_local std::string g_err;
 void set_error(const std::string &m) { g_err = m; }
 const char *last_error() { return g_err.c_str(); }
 
+// registry of every object that owns per-stream scratch (see StreamWorks)
+namespace {
+std::mutex &scoped_mu() {
+    static std::mutex m;
+    return m;
+}
+std::vector<StreamScoped *> &scoped_all() {
+    static std::vector<StreamScoped *> v;
+    return v;
+}
+}  // namespace
+StreamScoped::StreamScoped() {
+    std::lock_guard<std::mutex> g(scoped_mu());
+    scoped_all().push_back(this);
+}
+StreamScoped::~StreamScoped() {
+    std::lock_guard<std::mutex> g(scoped_mu());
+    auto &v = scoped_all();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] == this) {
+            v[i] = v.back();
+            v.pop_back();
+            break;
+        }
+}
+void drop_stream_everywhere(hipStream_t s) {
+    std::lock_guard<std::mutex> g(scoped_mu());
+    for (StreamScoped *o : scoped_all()) o->drop_stream(s);
+}
+
 // ---------------------------------------------------------------------------------------------- profiler
 hipEvent_t Profiler::get_event() {
     if (!pool.empty()) {
@@ -59,8 +89,8 @@ Profiler::~Profiler() {
 }
 
 int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s) {
-    ctx->n_launch[FAM_CONV] += 1;
-    ctx->n_flops[FAM_CONV] += conv_gemm_flops(p);
+    ctx->n_launch[FAM_CONV].fetch_add(1, std::memory_order_relaxed);
+    atomic_add(ctx->n_flops[FAM_CONV], conv_gemm_flops(p));
     if (ctx->prof.on) {
         ctx->prof.begin(FAM_CONV, s);
         ctx->prof.flops[FAM_CONV] += conv_gemm_flops(p);
@@ -80,8 +110,8 @@ int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s) {
 }
 
 int run_skinny(ts_ctx *ctx, const SkinnyParams &p, hipStream_t s) {
-    ctx->n_launch[FAM_SKINNY] += 1;
-    ctx->n_flops[FAM_SKINNY] += 2.0 * p.M * (double)p.N * p.Ktot;
+    ctx->n_launch[FAM_SKINNY].fetch_add(1, std::memory_order_relaxed);
+    atomic_add(ctx->n_flops[FAM_SKINNY], 2.0 * p.M * (double)p.N * p.Ktot);
     if (ctx->prof.on) {
         ctx->prof.begin(FAM_SKINNY, s);
         ctx->prof.flops[FAM_SKINNY] += 2.0 * p.M * (double)p.N * p.Ktot;
@@ -95,8 +125,8 @@ int run_skinny(ts_ctx *ctx, const SkinnyParams &p, hipStream_t s) {
 int run_skinny_batch(ts_ctx *ctx, const SkinnyParams *const *ps, int n, hipStream_t s) {
     double fl = 0;
     for (int i = 0; i < n; ++i) fl += 2.0 * ps[i]->M * (double)ps[i]->N * ps[i]->Ktot;
-    ctx->n_launch[FAM_SKINNY] += 1;
-    ctx->n_flops[FAM_SKINNY] += fl;
+    ctx->n_launch[FAM_SKINNY].fetch_add(1, std::memory_order_relaxed);
+    atomic_add(ctx->n_flops[FAM_SKINNY], fl);
     if (ctx->prof.on) {
         ctx->prof.begin(FAM_SKINNY, s);
         ctx->prof.flops[FAM_SKINNY] += fl;
@@ -320,12 +350,8 @@ struct ts_convnet {   // encoder trunk: project, stack, down, stack, down, stack
         Pool pool;
         DevBuf xin;   // padded copy of the input when in_dim % 32 != 0
     };
-    std::map<hipStream_t, std::unique_ptr<Work>> works;
-    Work &work(hipStream_t s) {
-        auto &w = works[s];
-        if (!w) w.reset(new Work());
-        return *w;
-    }
+    StreamWorks<Work> works;
+    Work &work(hipStream_t s) { return works.get(s); }
 };
 
 namespace {
@@ -478,12 +504,8 @@ struct ts_vqvae {
         Pool pool;
         DevBuf z, lat;   // encoder output (B*H, emb), internal latents (B*H) int64
     };
-    std::map<hipStream_t, std::unique_ptr<Work>> works;
-    Work &work(hipStream_t s) {
-        auto &w = works[s];
-        if (!w) w.reset(new Work());
-        return *w;
-    }
+    StreamWorks<Work> works;
+    Work &work(hipStream_t s) { return works.get(s); }
 };
 
 namespace {
@@ -515,7 +537,7 @@ int vq_encode_n(int n, ts_vqvae *const *vq, const float *const *poses, int poses
             TS_HIP(launch_vq_argmin(zp[i], vq[i]->emb, B * H, vq[i]->codebook.f(), vq[i]->code_sq.f(), vq[i]->ncode, vq[i]->emb,
                                     lat_out[i], 1, s));
             if (q_out && q_out[i])
-                TS_HIP(launch_gather_rows(vq[i]->codebook.f(), vq[i]->emb, lat_out[i], 1, B * H, vq[i]->emb, q_out[i], vq[i]->emb, s));
+                TS_HIP(launch_gather_rows(vq[i]->codebook.f(), vq[i]->emb, vq[i]->ncode, lat_out[i], 1, B * H, vq[i]->emb, q_out[i], vq[i]->emb, s));
         }
     }
     *Hout = H;
@@ -542,7 +564,7 @@ int vq_decode_n(int n, ts_vqvae *const *vq, const int64_t *const *lat, int B, in
         pool[i] = &vq[i]->work(s).pool;
         TS_TRY(pool[i]->ensure((size_t)B * H * hid));
         MiscScope ms(ctx, s);
-        TS_HIP(launch_gather_rows(vq[i]->aft_table.f(), hid, lat[i], 1, B * H, hid, pool[i]->buf(0), hid, s));
+        TS_HIP(launch_gather_rows(vq[i]->aft_table.f(), hid, vq[i]->ncode, lat[i], 1, B * H, hid, pool[i]->buf(0), hid, s));
     }
     int cur = 0, o = 0, L = H;
     const ConvLayer *Lp[2];

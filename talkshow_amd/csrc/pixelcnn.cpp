@@ -724,7 +724,7 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
         MiscScope ms(ctx, s);
         // class conditioning rows: CR[l][b] = class_cond_embedding_l[label[b]]  (h of gated_pixelcnn_v2.py:65)
         for (int l = 0; l < NL; ++l)
-            TS_HIP(launch_gather_rows(p->cls[l]->f(), 2 * D, label, 1, B, 2 * D, w->CR.f() + (size_t)l * B * 2 * D, 2 * D, s));
+            TS_HIP(launch_gather_rows(p->cls[l]->f(), 2 * D, p->NC, label, 1, B, 2 * D, w->CR.f() + (size_t)l * B * 2 * D, 2 * D, s));
         // known codes: the continuity prefix, and every position when teacher forced
         if (H0 > 0 || mode == TS_TEACHER_FORCED) {
             int64_t *tf = static_cast<int64_t *>(w->tfcodes.p);

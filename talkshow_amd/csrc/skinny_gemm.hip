@@ -340,24 +340,25 @@ typedef __attribute__((address_space(1))) float gf;
 typedef __attribute__((address_space(1))) const int gci;
 typedef __attribute__((address_space(1))) const f32x4 gcf4;
 
-template <int CNT, bool HALF>
-__device__ __forceinline__ void skinny16_load(gcf *ap0, gcf *ap1, gcf *bp, f32x4 (&a0)[8], f32x4 (&a1)[8], f32x4 (&b)[8]) {
+template <int V> struct IC { static constexpr int value = V; };
+
+// One q-step (16 k) of a wave: RB row blocks x CB column blocks of 16x16 outputs share RB + CB 16-byte operand loads.
+template <int RB, int CB>
+__device__ __forceinline__ void skinny16_load_step(gcf *const (&ap)[4], gcf *const (&bp)[2], int u, f32x4 (&a)[4], f32x4 (&b)[2]) {
 #pragma unroll
-    for (int u = 0; u < CNT; ++u) {
-        b[u] = *reinterpret_cast<gcf4 *>(bp + u * 16);
-        a0[u] = *reinterpret_cast<gcf4 *>(ap0 + u * 16);
-        if (!HALF) a1[u] = *reinterpret_cast<gcf4 *>(ap1 + u * 16);
-    }
+    for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<gcf4 *>(bp[c] + u * 16);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<gcf4 *>(ap[r] + u * 16);
 }
-template <int CNT, bool HALF>
-__device__ __forceinline__ void skinny16_mfma(const f32x4 (&a0)[8], const f32x4 (&a1)[8], const f32x4 (&b)[8], f32x4 &acc0, f32x4 &acc1) {
+template <int RB, int CB>
+__device__ __forceinline__ void skinny16_mfma_step(const f32x4 (&a)[4], const f32x4 (&b)[2], f32x4 (&acc)[8]) {
 #pragma unroll
-    for (int u = 0; u < CNT; ++u)
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u][e], b[u][e], acc0, 0, 0, 0);
-            if (!HALF) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][e], b[u][e], acc1, 0, 0, 0);
-        }
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+                acc[r * CB + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][e], b[c][e], acc[r * CB + c], 0, 0, 0);
 }
 
 // TRACE instrumentation (tools/skinny_trace.py): workgroup (0,0,0), wave 0 stamps the 100 MHz wall clock at five points
@@ -368,13 +369,18 @@ constexpr size_t TRACE_SLOTS = (size_t)TRACE_WGS * TRACE_LAUNCHES;
 __device__ unsigned long long *g_trace;   // [TRACE_SLOTS][TRACE_REC], allocated by skinny_init when TS_SKINNY_TRACE is set
 static unsigned g_trace_seq = 0;          // host: sequence number handed to the next traced launch
 
-// HALF: 16-row tiles (one MFMA row block): a workgroup fetches 16 instead of 32 activation rows — the A operand is 2/3 of a
-// 32-row workgroup's bytes and a stage is bounded by what one CU can fetch — used when the launch still fits one
-// workgroup per CU.
-template <int W, bool HALF = false, bool TRACE = false>
-__global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescBatch batch) {
-    constexpr int ROWS = HALF ? 16 : 32;
-    constexpr int NREG = HALF ? 4 : 8;          // accumulator registers per lane to reduce across the waves
+// Tile = RB x CB blocks of 16 x 16 outputs (one v_mfma_f32_16x16x4_f32 accumulator each):
+//   (1,1) 16 rows x 16 columns   a single chain whose launch still fits one workgroup per CU: least bytes per CU
+//   (2,1) 32 x 16                one batch of <= 32 clips
+//   (2,2) 32 x 32, (4,2) 64 x 32 coalesced batches (M >= 64 clips per stage): the stage turns from latency- into
+//                                L2-bandwidth-bound, and a tile's operand bytes per output go 256 / 192 -> 128 / 96 B
+// Every block of every tile shape is accumulated in the same order (same K split over the waves, same MFMA, same LDS
+// summation order), so a clip's result does not depend on the tile shape its batch happened to get: bit-identical.
+template <int W, int RB, int CB, bool TRACE = false>
+__global__ __launch_bounds__(W * 64, (RB * CB > 4 ? W / 2 : 1)) void skinny16_fast_kernel(const SkinnyDescBatch batch) {
+    constexpr int ROWS = RB * 16;
+    constexpr int NBLK = RB * CB;
+    constexpr int NREG = NBLK * 4;              // accumulator registers per lane to reduce across the waves
     __shared__ float red[W][NREG][64];
     __shared__ unsigned long long wave_t[TRACE ? W : 1][2];
     unsigned long long tr[5] = {0, 0, 0, 0, 0};
@@ -403,22 +409,27 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
         return (gcf *)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(dw, k + 1) << 32) |
                        (uint64_t)(uint32_t)__builtin_amdgcn_readlane(dw, k));
     };
-    const int gx = I(SD_GX);
+    const int gx = I(SD_GX) / CB;               // column tiles of this shape (SD_GX counts 16-column tiles)
     const int mt = (bx - first) / gx, tile = (bx - first) - mt * gx;
     if (TRACE) tr[1] = wall_clock64();
 
     const int M = I(SD_M), N = I(SD_N), flags = I(SD_FLAGS), gateD = I(SD_GATED);
     const bool gate = flags & SDF_GATE;
-    int n;
-    if (gate) {
-        const int tiles_per_group = gateD >> 3;
-        const int group = tile / tiles_per_group, ch0 = (tile - group * tiles_per_group) << 3;
-        n = group * 2 * gateD + (li >> 3) * gateD + ch0 + (li & 7);
-    } else {
-        n = tile * 16 + li;
+    int n[CB], nc[CB];
+    bool n_ok[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+        const int t16 = tile * CB + c;
+        if (gate) {
+            const int tiles_per_group = gateD >> 3;
+            const int group = t16 / tiles_per_group, ch0 = (t16 - group * tiles_per_group) << 3;
+            n[c] = group * 2 * gateD + (li >> 3) * gateD + ch0 + (li & 7);
+        } else {
+            n[c] = t16 * 16 + li;
+        }
+        n_ok[c] = n[c] < N;
+        nc[c] = n_ok[c] ? n[c] : 0;
     }
-    const bool n_ok = n < N;
-    const int nc = n_ok ? n : 0;
 
     // ---- this wave's K range: CNT q-steps (16 k each) inside one segment ----
     const int cnt = I(SD_CNT);
@@ -440,63 +451,107 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
     gcf *base = P(sbase);
     gci *gidx = (gci *)P(sbase + 2);
     const int row_stride = I(sbase + 4), row_shift = I(sbase + 6);
-    const int m0 = mt * ROWS + li, m1 = HALF ? m0 : m0 + 16;
-    const int m0c = m0 < M ? m0 : M - 1, m1c = m1 < M ? m1 : M - 1;   // clamped rows: computed, never stored
-    gcf *ar0, *ar1;
-    if (gidx) {   // wave-uniform: token-embedding gather (one extra round trip, first stage of column 1 only)
-        const int gstride = I(sbase + 5);
-        const int g0 = gidx[(long)m0c * gstride], g1 = gidx[(long)m1c * gstride];
-        gcf *zero = P(SD_ZERO);
-        ar0 = g0 >= 0 ? base + (long)g0 * row_stride : zero;
-        ar1 = g1 >= 0 ? base + (long)g1 * row_stride : zero;
-    } else {
-        ar0 = base + (long)(m0c >> row_shift) * row_stride;
-        ar1 = base + (long)(m1c >> row_shift) * row_stride;
-    }
     const int koff = (q0 - qs) * 16 + lg * 4;
-    gcf *bp = P(SD_W) + (long)nc * I(SD_LDW) + q0 * 16 + lg * 4;
+    gcf *ap[4], *bp[2];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int m = mt * ROWS + r * 16 + li;
+        const int mc = m < M ? m : M - 1;   // clamped rows: computed, never stored
+        if (gidx) {   // wave-uniform: token-embedding gather (one extra round trip, first stage of column 1 only)
+            const int g = gidx[(long)mc * I(sbase + 5)];
+            ap[r] = (g >= 0 ? base + (long)g * row_stride : P(SD_ZERO)) + koff;
+        } else {
+            ap[r] = base + (long)(mc >> row_shift) * row_stride + koff;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c) bp[c] = P(SD_W) + (long)nc[c] * I(SD_LDW) + q0 * 16 + lg * 4;
 
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[8];
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int RPW = NREG >= W ? NREG / W : 1;   // registers finished by each (active) wave
-    const bool active = wave * RPW < NREG;          // HALF with 8 waves: waves 4..7 only contribute partial sums
+    const bool active = wave * RPW < NREG;          // (1,1) with 8 waves: waves 4..7 only contribute partial sums
     float e_add[RPW], e_cls[RPW];
     auto epilogue_operands = [&]() {
         if (!active) return;
 #pragma unroll
         for (int rr = 0; rr < RPW; ++rr) {
             const int r = wave * RPW + rr;
-            const int row = mt * ROWS + (r >> 2) * 16 + lg * 4 + (r & 3);
+            const int blk = r >> 2, rb = blk / CB, cb = blk - rb * CB;
+            const int row = mt * ROWS + rb * 16 + lg * 4 + (r & 3);
             const int rowc = row < M ? row : 0;
-            const float t0 = P(SD_BIAS)[nc];
-            const float t1 = P(SD_ADD1)[(long)(rowc >> I(SD_ADD1_SHIFT)) * I(SD_ADD1_STRIDE) + nc];
-            const float t2 = P(SD_ADD2)[(long)(rowc >> I(SD_ADD2_SHIFT)) * I(SD_ADD2_STRIDE) + nc];
-            const float t3 = P(SD_ADD3)[(long)rowc * I(SD_ADD3_STRIDE) + nc];
+            const int ncol = nc[cb];
+            const float t0 = P(SD_BIAS)[ncol];
+            const float t1 = P(SD_ADD1)[(long)(rowc >> I(SD_ADD1_SHIFT)) * I(SD_ADD1_STRIDE) + ncol];
+            const float t2 = P(SD_ADD2)[(long)(rowc >> I(SD_ADD2_SHIFT)) * I(SD_ADD2_STRIDE) + ncol];
+            const float t3 = P(SD_ADD3)[(long)rowc * I(SD_ADD3_STRIDE) + ncol];
             const int cls_ld = I(SD_CLS_LD);
-            e_cls[rr] = P(SD_CLS)[(long)rowc * cls_ld + (nc % cls_ld)];
+            e_cls[rr] = P(SD_CLS)[(long)rowc * cls_ld + (ncol % cls_ld)];
             e_add[rr] = ((t0 + t1) + t2) + t3;
         }
     };
-    // phase 1: every load of this wave — K operands first (they are waited for first), then the epilogue operands
-    f32x4 a0[8], a1[8], b[8];
-    if (cnt == 8) skinny16_load<8, HALF>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
-    else if (cnt == 4) skinny16_load<4, HALF>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
-    else if (cnt == 2) skinny16_load<2, HALF>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
-    else if (cnt == 1) skinny16_load<1, HALF>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
-    else skinny16_load<3, HALF>(ar0 + koff, ar1 + koff, bp, a0, a1, b);
-    epilogue_operands();
-    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from sinking loads between the MFMAs
     unsigned long long t_loads = 0;
-    if (TRACE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        t_loads = wall_clock64();
+    if (NBLK <= 2) {
+        // phase 1: every load of this wave — K operands first (they are waited for first), then the epilogue operands;
+        // phase 2: the MFMAs.  Straight-line code per q-step count.
+        f32x4 a[8][4], b[8][2];
+        auto phase1 = [&](auto cnt_c) {
+            constexpr int CNT = decltype(cnt_c)::value;
+#pragma unroll
+            for (int u = 0; u < CNT; ++u) skinny16_load_step<RB, CB>(ap, bp, u, a[u], b[u]);
+        };
+        auto phase2 = [&](auto cnt_c) {
+            constexpr int CNT = decltype(cnt_c)::value;
+#pragma unroll
+            for (int u = 0; u < CNT; ++u) skinny16_mfma_step<RB, CB>(a[u], b[u], acc);
+        };
+        if (cnt == 8) phase1(IC<8>{});
+        else if (cnt == 4) phase1(IC<4>{});
+        else if (cnt == 2) phase1(IC<2>{});
+        else if (cnt == 1) phase1(IC<1>{});
+        else phase1(IC<3>{});
+        epilogue_operands();
+        __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from sinking loads between the MFMAs
+        if (TRACE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            t_loads = wall_clock64();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (cnt == 8) phase2(IC<8>{});
+        else if (cnt == 4) phase2(IC<4>{});
+        else if (cnt == 2) phase2(IC<2>{});
+        else if (cnt == 1) phase2(IC<1>{});
+        else phase2(IC<3>{});
+    } else {
+        // fat tiles (cnt <= 4, host-checked): (RB + CB) x cnt 16-byte loads would not leave room for a second workgroup on
+        // the CU, so the A operand is fetched two q-steps ahead while the (shared, colder) weight rows all go out at once
+        f32x4 a[2][4], b[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < cnt) {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) b[u][c] = *reinterpret_cast<gcf4 *>(bp[c] + u * 16);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (u < cnt) {
+#pragma unroll
+                for (int r = 0; r < RB; ++r) a[u][r] = *reinterpret_cast<gcf4 *>(ap[r] + u * 16);
+            }
         __builtin_amdgcn_sched_barrier(0);
+        if (TRACE) t_loads = wall_clock64();
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < cnt) {
+                skinny16_mfma_step<RB, CB>(a[u & 1], b[u], acc);
+                if (u + 2 < cnt) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) a[u & 1][r] = *reinterpret_cast<gcf4 *>(ap[r] + (u + 2) * 16);
+                }
+            }
+        epilogue_operands();   // issued behind the last MFMAs (not live during the main loop: registers)
     }
-    // phase 2
-    if (cnt == 8) skinny16_mfma<8, HALF>(a0, a1, b, acc0, acc1);
-    else if (cnt == 4) skinny16_mfma<4, HALF>(a0, a1, b, acc0, acc1);
-    else if (cnt == 2) skinny16_mfma<2, HALF>(a0, a1, b, acc0, acc1);
-    else if (cnt == 1) skinny16_mfma<1, HALF>(a0, a1, b, acc0, acc1);
-    else skinny16_mfma<3, HALF>(a0, a1, b, acc0, acc1);
     if (TRACE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tr[2] = wall_clock64();
@@ -504,10 +559,9 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
     }
 
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        red[wave][r][lane] = acc0[r];
-        if (!HALF) red[wave][4 + r][lane] = acc1[r];
-    }
+    for (int k = 0; k < NBLK; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][k * 4 + r][lane] = acc[k][r];
     __syncthreads();
     if (TRACE) tr[3] = wall_clock64();
 
@@ -519,22 +573,24 @@ __global__ __launch_bounds__(W * 64) void skinny16_fast_kernel(const SkinnyDescB
         float v = red[0][r][lane];
 #pragma unroll
         for (int w = 1; w < W; ++w) v += red[w][r][lane];
-        const int row = mt * ROWS + (r >> 2) * 16 + lg * 4 + (r & 3);
-        const bool ok = n_ok && row < M;
+        const int blk = r >> 2, rb = blk / CB, cb = blk - rb * CB;
+        const int row = mt * ROWS + rb * 16 + lg * 4 + (r & 3);
+        const bool ok = n_ok[cb] && row < M;
         v += e_add[rr];
         if (gate) {
-            if ((flags & SDF_PRE) && ok) ((gf *)P(SD_PRE))[(long)row * I(SD_PRE_STRIDE) + n] = v;
+            if ((flags & SDF_PRE) && ok) ((gf *)P(SD_PRE))[(long)row * I(SD_PRE_STRIDE) + n[cb]] = v;
             v += e_cls[rr];
             const float partner = __shfl_xor(v, 8);
             if ((li & 8) == 0 && ok) {
                 const float g = tanhf(v) * (1.0f / (1.0f + expf(-partner)));
+                const int t16 = tile * CB + cb;
                 const int tiles_per_group = gateD >> 3;
-                const int group = tile / tiles_per_group, ch0 = (tile - group * tiles_per_group) << 3;
+                const int group = t16 / tiles_per_group, ch0 = (t16 - group * tiles_per_group) << 3;
                 out[(long)row * out_stride + group * gateD + ch0 + (li & 7)] = g;
             }
         } else {
             if (flags & SDF_RELU) v = v > 0.f ? v : 0.f;
-            if (ok) out[(long)row * out_stride + n] = v;
+            if (ok) out[(long)row * out_stride + n[cb]] = v;
         }
     }
     if (TRACE && tid == 0) {
@@ -683,34 +739,68 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
         if (variant != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_zero[dev]) {
             SkinnyDescBatch db;
             bool fast = true;
-            // 16-row tiles when the launch then still fits one workgroup per CU (less to fetch per CU), else 32-row tiles
+            // Tile shape (rows x columns in blocks of 16).  One batch (M <= 32): 16-row tiles when the launch then still
+            // fits one workgroup per CU (less to fetch per CU), else 32 x 16.  Coalesced batches (M >= 64): the biggest of
+            // 64 x 32 / 32 x 32 / 32 x 16 that still spreads the launch over about all CUs (fewer operand bytes per output).
             static const int half_max = [] { const char *e = getenv("TS_SKINNY_HALF_MAX"); return e ? atoi(e) : 256; }();
-            int total16 = 0;
-            for (int i = 0; i < n; ++i) total16 += b.p[i].grid_x * ((b.p[i].M + 15) / 16);
-            const bool half = total16 <= half_max;
+            static const int fat_min = [] { const char *e = getenv("TS_SKINNY_FAT_MIN"); return e ? atoi(e) : 200; }();
+            static const int force_shape = [] { const char *e = getenv("TS_SKINNY_SHAPE"); return e ? atoi(e) : 0; }();   // 11, 21, 22, 42
+            int maxM = 0, maxcnt = 0;
+            bool even = true;
+            for (int i = 0; i < n; ++i) {
+                maxM = maxM > b.p[i].M ? maxM : b.p[i].M;
+                const int c = b.p[i].Ktot / (16 * W16);
+                maxcnt = maxcnt > c ? maxcnt : c;
+                if (b.p[i].grid_x % 2) even = false;
+            }
+            auto count = [&](int rows, int cb) {
+                int t = 0;
+                for (int i = 0; i < n; ++i) t += (b.p[i].grid_x / cb) * ((b.p[i].M + rows - 1) / rows);
+                return t;
+            };
+            int RB = 2, CB = 1;
+            if (force_shape) {
+                RB = force_shape / 10;
+                CB = force_shape % 10;
+                if (!even || maxcnt > 4) CB = 1;
+                if (CB == 1 && RB > 2) RB = 2;
+            } else if (maxM <= 32) {
+                if (count(16, 1) <= half_max) RB = 1;
+            } else if (even && maxcnt <= 4) {
+                if (count(64, 2) >= fat_min) { RB = 4; CB = 2; }
+                else if (count(32, 2) >= fat_min) { RB = 2; CB = 2; }
+            }
+            const int rows = RB * 16;
             int total = 0;
             for (int i = 0; i < 8; ++i) db.start[i] = 0x7fffffff;
             for (int i = 0; i < n && fast; ++i) {
                 fast = skinny_pack_desc(b.p[i], W16, g_zero[dev], db.d[i]);
                 db.start[i] = total;
-                total += b.p[i].grid_x * (half ? (b.p[i].M + 15) / 16 : b.p[i].grid_y);
+                total += (b.p[i].grid_x / CB) * ((b.p[i].M + rows - 1) / rows);
             }
             for (int i = n; i < SKINNY_MAX_PROBLEMS; ++i) std::memset(&db.d[i], 0, sizeof(SkinnyDesc));
             if (fast) {
                 const dim3 grid(total);
                 static const int trace = [] { const char *e = getenv("TS_SKINNY_TRACE"); return e ? atoi(e) : 0; }();
                 if (trace) db.start[7] = (int)(g_trace_seq++);
-                const int sel = (W16 == 8 ? 0 : 4) + (half ? 2 : 0) + (trace ? 1 : 0);
-                switch (sel) {
-                    case 0: hipLaunchKernelGGL((skinny16_fast_kernel<8, false, false>), grid, dim3(512), 0, stream, db); break;
-                    case 1: hipLaunchKernelGGL((skinny16_fast_kernel<8, false, true>), grid, dim3(512), 0, stream, db); break;
-                    case 2: hipLaunchKernelGGL((skinny16_fast_kernel<8, true, false>), grid, dim3(512), 0, stream, db); break;
-                    case 3: hipLaunchKernelGGL((skinny16_fast_kernel<8, true, true>), grid, dim3(512), 0, stream, db); break;
-                    case 4: hipLaunchKernelGGL((skinny16_fast_kernel<4, false, false>), grid, dim3(256), 0, stream, db); break;
-                    case 5: hipLaunchKernelGGL((skinny16_fast_kernel<4, false, true>), grid, dim3(256), 0, stream, db); break;
-                    case 6: hipLaunchKernelGGL((skinny16_fast_kernel<4, true, false>), grid, dim3(256), 0, stream, db); break;
-                    default: hipLaunchKernelGGL((skinny16_fast_kernel<4, true, true>), grid, dim3(256), 0, stream, db); break;
+                const int shape = RB * 10 + CB;
+#define TS_SK_LAUNCH(Wv, R, C)                                                                                         \
+    do {                                                                                                               \
+        if (trace) hipLaunchKernelGGL((skinny16_fast_kernel<Wv, R, C, true>), grid, dim3(Wv * 64), 0, stream, db);     \
+        else hipLaunchKernelGGL((skinny16_fast_kernel<Wv, R, C, false>), grid, dim3(Wv * 64), 0, stream, db);          \
+    } while (0)
+                if (W16 == 8) {
+                    if (shape == 11) TS_SK_LAUNCH(8, 1, 1);
+                    else if (shape == 21) TS_SK_LAUNCH(8, 2, 1);
+                    else if (shape == 22) TS_SK_LAUNCH(8, 2, 2);
+                    else TS_SK_LAUNCH(8, 4, 2);
+                } else {
+                    if (shape == 11) TS_SK_LAUNCH(4, 1, 1);
+                    else if (shape == 21) TS_SK_LAUNCH(4, 2, 1);
+                    else if (shape == 22) TS_SK_LAUNCH(4, 2, 2);
+                    else TS_SK_LAUNCH(4, 4, 2);
                 }
+#undef TS_SK_LAUNCH
                 return hipGetLastError();
             }
         }

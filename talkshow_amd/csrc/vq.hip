@@ -121,19 +121,25 @@ hipError_t launch_row_sqnorm(const float *e, int n, int dim, float *out, hipStre
 // one wave per row, 16-byte lanes
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ table, int ld_table,
                                                           const int64_t *__restrict__ idx, long idx_stride, int M,
-                                                          int width, float *__restrict__ out, int ldo) {
+                                                          int width, float *__restrict__ out, int ldo, int nrows) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int lane = threadIdx.x & 63;
-    const float4 *src = reinterpret_cast<const float4 *>(table + idx[(long)m * idx_stride] * ld_table);
+    const int64_t r = idx[(long)m * idx_stride];
     float4 *dst = reinterpret_cast<float4 *>(out + (long)m * ldo);
+    if (r < 0 || r >= nrows) {   // nn.Embedding would raise IndexError; here: memory-safe and loud (a row of NaNs)
+        const float q = __builtin_nanf("");
+        for (int c = lane; c < width / 4; c += 64) dst[c] = make_float4(q, q, q, q);
+        return;
+    }
+    const float4 *src = reinterpret_cast<const float4 *>(table + r * ld_table);
     for (int c = lane; c < width / 4; c += 64) dst[c] = src[c];
 }
-hipError_t launch_gather_rows(const float *table, int ld_table, const int64_t *idx, long idx_stride, int M, int width,
-                              float *out, int ldo, hipStream_t stream) {
+hipError_t launch_gather_rows(const float *table, int ld_table, int nrows, const int64_t *idx, long idx_stride, int M,
+                              int width, float *out, int ldo, hipStream_t stream) {
     if (width % 4 || ld_table % 4 || ldo % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, table, ld_table, idx, idx_stride,
-                       M, width, out, ldo);
+                       M, width, out, ldo, nrows);
     return hipGetLastError();
 }
 

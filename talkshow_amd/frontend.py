@@ -13,10 +13,13 @@ path and no kernel parity claim depends on it):
     (f_min 0, f_max sr/2, norm None), `10*log10(clamp(x, 1e-10))`, clamp at (per-clip max - 80 dB), orthonormal
     DCT-II (256 -> 64).
 
-PARITY UNPINNED: neither library is available here to generate golden vectors, and the reference ships none
-(SURVEY.md §8c); tests/test_frontend.py checks the restatement against an independent float64 evaluation of the same
-formulae and against closed-form cases.  Everything downstream (the hot path) is pinned on feature arrays, which is
-also what `aud_fn` may be directly: a `(T, 64)` float array / tensor, or a `.npy` file of one.
+Parity: torchaudio / librosa cannot be run here and the reference ships no vectors, so the stages are
+pinned against the installed third-party implementations of the same definitions (tests/test_frontend.py): STFT / power
+<-> `torch.stft` (what torchaudio's Spectrogram calls); HTK mel filterbank and dB / top_db <-> `transformers.audio_utils`;
+DCT-II <-> `scipy.fft.dct`; whole MFCC <-> the pipeline assembled from those.  STILL UNPINNED: the sinc-Hann resampler
+(and librosa's kaiser resampler of the face path), checked on closed-form properties only.  Everything downstream
+(the hot path) is pinned on feature arrays, which is also what `aud_fn` may be directly: a `(T, 64)` float array /
+tensor, or a `.npy` file of one.
 """
 import math
 import os
@@ -99,20 +102,32 @@ def create_dct(n_mfcc, n_mels):
     return dct.T.astype(F32)
 
 
-def mfcc(wave, sample_rate, n_mfcc=64, n_fft=2048, hop_length=734, n_mels=256, top_db=80.0):
-    """torchaudio.transforms.MFCC(sample_rate, n_mfcc, melkwargs={n_fft, n_mels, hop_length, mel_scale='htk'}) on a
-    mono waveform (N,) -> (n_mfcc, T) with T = N // hop + 1 (`center=True`)."""
+def power_spectrogram(wave, n_fft=2048, hop_length=734):
+    """torchaudio.transforms.Spectrogram(n_fft, hop_length, power=2) == |torch.stft(..., window=hann_window(n_fft,
+    periodic=True), center=True, pad_mode='reflect', onesided=True)|^2 on a mono waveform (N,) -> (T, n_fft//2+1),
+    T = N // hop + 1.  This stage IS pinned: tests/test_frontend.py compares it with torch.stft (installed), the function
+    torchaudio's Spectrogram calls."""
     from scipy import fft as sfft
     x = np.pad(np.asarray(wave, dtype=F32), (n_fft // 2, n_fft // 2), mode="reflect")
     T = 1 + (x.shape[0] - n_fft) // hop_length
     frames = np.lib.stride_tricks.sliding_window_view(x, n_fft)[::hop_length][:T]
     window = (0.5 - 0.5 * np.cos(2.0 * math.pi * np.arange(n_fft) / n_fft)).astype(F32)          # periodic Hann
     spec = sfft.rfft(frames * window[None, :], axis=1)                                             # float32 -> complex64
-    power = (spec.real.astype(F32) ** 2 + spec.imag.astype(F32) ** 2).astype(F32)                 # (T, 1025)
+    return (spec.real.astype(F32) ** 2 + spec.imag.astype(F32) ** 2).astype(F32)                  # (T, 1025)
+
+
+def mfcc_from_power(power, sample_rate, n_mfcc=64, n_fft=2048, n_mels=256, top_db=80.0):
+    """MelScale(htk, norm None) -> AmplitudeToDB('power', top_db=80, per-clip max) -> DCT-II ortho: (T, n_freq) -> (n_mfcc, T)."""
     mel = power @ melscale_fbanks(n_fft // 2 + 1, 0.0, float(sample_rate // 2), n_mels, sample_rate)   # (T, n_mels)
     db = (10.0 * np.log10(np.maximum(mel, F32(1e-10)))).astype(F32)                                # ref = 1 -> no offset
     db = np.maximum(db, db.max() - F32(top_db))                                                    # per-clip max
     return np.ascontiguousarray((db @ create_dct(n_mfcc, n_mels)).T, dtype=F32)
+
+
+def mfcc(wave, sample_rate, n_mfcc=64, n_fft=2048, hop_length=734, n_mels=256, top_db=80.0):
+    """torchaudio.transforms.MFCC(sample_rate, n_mfcc, melkwargs={n_fft, n_mels, hop_length, mel_scale='htk'}) on a
+    mono waveform (N,) -> (n_mfcc, T) with T = N // hop + 1 (`center=True`)."""
+    return mfcc_from_power(power_spectrogram(wave, n_fft, hop_length), sample_rate, n_mfcc, n_fft, n_mels, top_db)
 
 
 def _hop(fps):
@@ -154,7 +169,8 @@ def _mfcc_on_device(wave_mono, sr_in, sr, fps):
     return _device_mfcc[key](wave_mono)[0].cpu().numpy()
 
 
-def get_mfcc_ta(aud_fn, sr=22000, fps=30, smlpx=True, type='mfcc', am=None, am_sr=None, encoder_choice='mfcc', host=None):
+def get_mfcc_ta(aud_fn, eps=1e-6, fps=15, smlpx=False, sr=16000, n_mfcc=64, win_size=None, type='mfcc', am=None, am_sr=None,
+                encoder_choice='mfcc', host=None):
     """`get_mfcc_ta` (`utils.py:148-231`), body branch: -> (T, 64) float32 features.
 
     wav files: resample + MFCC run on the GPU (ts_mfcc_forward) when a HIP device is present, else on the host in numpy
@@ -176,12 +192,12 @@ def get_mfcc_ta(aud_fn, sr=22000, fps=30, smlpx=True, type='mfcc', am=None, am_s
     return feat
 
 
-def get_mfcc_sepa(aud_fn, sr=22000, fps=30):
+def get_mfcc_sepa(aud_fn, fps=15, sr=16000, host=None):
     """`get_mfcc_sepa` (`utils.py:234-263`): MFCCs of the first 2 s and of the rest, concatenated, + the split frame."""
     feat = _features_from_any(aud_fn)
     if feat is not None:
         feat = np.asarray(feat, dtype=np.float32)
-        return feat, 2 * fps + 1
+        return feat, 1 + (2 * sr) // _hop(fps)      # MFCC length of the first 2 s (center=True): the wav path's split
     wave = _load_mono_resampled(aud_fn, sr)
     f0 = mfcc(wave[:sr * 2], sr, hop_length=_hop(fps)).T
     f1 = mfcc(wave[sr * 2:], sr, hop_length=_hop(fps)).T

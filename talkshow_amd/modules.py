@@ -57,8 +57,12 @@ class NativeModule:
     def _after_load(self):
         pass
 
+    _BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked", "vq_layer.embeddings", "ema_dw.hidden",
+                        "ema_cluster_size.hidden")
+
     def parameters(self):
-        return (v for v in self._sd.values() if v.dtype == torch.float32)
+        # nn.Module.parameters() leaves buffers out (BatchNorm statistics, the EMA codebook of VectorQuantizerEMA)
+        return (v for k, v in self._sd.items() if v.dtype == torch.float32 and not k.endswith(self._BUFFER_SUFFIXES))
 
     def eval(self):
         self.training = False
@@ -96,17 +100,32 @@ class NativeModule:
         return self._device.index if self._device.index is not None else torch.cuda.current_device()
 
     def _ctx(self):
-        idx = self._require_hip()
-        torch.cuda.set_device(idx)
-        return _lib.context(idx)
+        return _lib.context(self._require_hip())
 
     def handle(self):
         if self._handle is None:
-            self._handle = self._create(self._ctx())
+            with torch.cuda.device(self._require_hip()):     # the caller's current device is left as it was
+                self._handle = self._create(self._ctx())
         return self._handle
 
     def _dev(self):
         return torch.device("cuda", self._require_hip())
+
+
+_range_ok = set()
+
+
+def _check_index_range(t, n, what):
+    """IndexError for indices outside [0, n) like nn.Embedding; the device->host sync is paid once per tensor version."""
+    key = (t.data_ptr(), t.numel(), t._version, n)
+    if key in _range_ok:
+        return
+    lo, hi = int(t.min()), int(t.max())
+    if lo < 0 or hi >= n:
+        raise IndexError(f"{what} out of range: [{lo}, {hi}] not within [0, {n})")
+    if len(_range_ok) > 256:
+        _range_ok.clear()
+    _range_ok.add(key)
 
 
 def _dev_f32(x, device):
@@ -250,6 +269,9 @@ class GatedPixelCNN(NativeModule):
         label = torch.as_tensor(label, dtype=torch.int64, device=dev).reshape(-1).contiguous()
         if label.numel() == 1 and B > 1:
             label = label.repeat(B)
+        if label.numel() != B:
+            raise ValueError(f"label must hold 1 or B={B} class indices, got {label.numel()}")
+        _check_index_range(label, self.n_classes, "class label")
         if mode == _lib.TS_TEACHER_FORCED:
             codes = torch.as_tensor(codes, dtype=torch.int64, device=dev).contiguous()
         else:

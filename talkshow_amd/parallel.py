@@ -44,10 +44,14 @@ def gather_sequences(local, n_total=None):
 
 
 def generate_sharded(generate_fn, mfcc, ids, batch=32):
-    """Run `generate_fn(mfcc_block, ids_block, clip_index0)` over this rank's shard in batches and all-gather.
+    """Run `generate_fn(mfcc_block, ids_block, clip_index0)` over THIS rank's shard in batches; no collective here.
 
     mfcc (N,T,64) / ids (N,) are the GLOBAL inputs (every rank holds them, or at least its own block).
-    generate_fn returns (codes, poses) for a block; returns (N,T',C) poses on every rank.
+    generate_fn returns (codes, poses (n,T',C)) for a block.  Returns (local poses (n_local,T',C), (start, stop)); hand
+    `local` to `gather_sequences` for the one exchange.  A rank whose shard is empty (fewer clips than ranks, or a
+    ragged tail) returns a (0,T',C) tensor with the right trailing shape, dtype and device for the collective:
+    generate_fn is asked for them with a zero-clip block (`mfcc[0:0]`), which the HIP wrapper answers without a launch
+    (`output_shape`), a stand-in by returning an empty result.
     """
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -60,10 +64,44 @@ def generate_sharded(generate_fn, mfcc, ids, batch=32):
         outs.append(poses)
     if outs:
         local = torch.cat(outs, 0)
-    else:   # empty shard: shape must still be known for the collective
-        probe = torch.zeros((0,), dtype=torch.float32)
-        local = probe
+    else:
+        local = _empty_like_output(generate_fn, mfcc, ids)
     return local, (a, b)
+
+
+def _empty_like_output(generate_fn, mfcc, ids):
+    """(0,T',C) tensor on the device / in the dtype generate_fn produces, for a rank with no clips."""
+    shape_fn = getattr(generate_fn, "output_shape", None)
+    if shape_fn is not None:
+        tail, dtype, device = shape_fn(mfcc)
+        return torch.zeros((0,) + tuple(tail), dtype=dtype, device=device)
+    _, probe = generate_fn(mfcc[0:0], ids[0:0], 0)
+    if probe.ndim < 2 or probe.shape[0] != 0:
+        raise RuntimeError("generate_fn must answer a zero-clip block with a (0,T',C) tensor (or expose output_shape)")
+    return probe
+
+
+def whole_body_local(body, face, mfcc, ids, wav, face_ids, mode=None, seed=0, clip_index0=0, batch_body=32, batch_face=64,
+                     stand=False):
+    """Whole-body generation of THIS rank's clips (no collective): body path in batches of `batch_body`, face path in
+    batches of `batch_face`, (n, Tf, 265) rows assembled on the GPU (`pose_index.assemble_full` = demo.py:207-229 +
+    part2full).  mfcc (n,T,64), ids (n,), wav (n,S) 16 kHz samples, face_ids (n,4); `clip_index0` = global index of
+    the first clip (Philox subsequences).  n = 0 gives a (0, Tf, 265) tensor on the current device."""
+    from . import _lib
+    from .pose_index import assemble_full
+    n = mfcc.shape[0]
+    frames = wav.shape[1] * 30 // 16000                       # smplx_face.py:203
+    mode = _lib.TS_SAMPLE_PHILOX if mode is None else mode
+    if n == 0:
+        return torch.zeros((0, frames, 265), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+    poses, faces = [], []
+    for s in range(0, n, batch_body):
+        e = min(s + batch_body, n)
+        poses.append(body.generate_batch(mfcc[s:e], ids[s:e], mode=mode, seed=seed, clip_index0=clip_index0 + s)[1])
+    for s in range(0, n, batch_face):
+        e = min(s + batch_face, n)
+        faces.append(face.generator.run(wav[s:e], face_ids[s:e], frames))
+    return assemble_full(torch.cat(poses, 0), torch.cat(faces, 0), stand=stand)
 
 
 def whole_body_sharded(body, face, mfcc, ids, wav, face_ids, mode=None, seed=0, batch_body=32, batch_face=64, stand=False):
@@ -71,29 +109,13 @@ def whole_body_sharded(body, face, mfcc, ids, wav, face_ids, mode=None, seed=0, 
 
     body / face: the `nets.s2g_body_pixel` / `nets.s2g_face` wrappers of this rank (full weight replicas).
     mfcc (N,T,64), ids (N,) int64 speaker indices, wav (N,S) 16 kHz samples, face_ids (N,4) one-hot / zero float vectors:
-    the GLOBAL inputs (a rank only touches its own block).  Each rank runs the body path in batches of `batch_body` and the
-    face path in batches of `batch_face` on its contiguous block, assembles (n_local, Tf, 265) rows on the GPU
-    (`pose_index.assemble_full` = demo.py:207-229 + part2full) and the ranks exchange them once.
-    Returns (all_rows (N,Tf,265) on every rank, (start, stop) of this rank's block).
+    the GLOBAL inputs (a rank only touches its own block).  Returns (all_rows (N,Tf,265) on every rank, (start, stop) of
+    this rank's block); a rank with an empty block contributes a (0,Tf,265) shard.
     """
-    from . import _lib
-    from .pose_index import assemble_full
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     n = mfcc.shape[0]
     a, b = shard_range(n, rank, world)
-    frames = wav.shape[1] * 30 // 16000                       # smplx_face.py:203
-    mode = _lib.TS_SAMPLE_PHILOX if mode is None else mode
-    poses, faces = [], []
-    for s in range(a, b, batch_body):
-        e = min(s + batch_body, b)
-        poses.append(body.generate_batch(mfcc[s:e], ids[s:e], mode=mode, seed=seed, clip_index0=s)[1])
-    for s in range(a, b, batch_face):
-        e = min(s + batch_face, b)
-        faces.append(face.generator.run(wav[s:e], face_ids[s:e], frames))
-    dev = torch.device("cuda", torch.cuda.current_device())
-    if poses:
-        local = assemble_full(torch.cat(poses, 0), torch.cat(faces, 0), stand=stand)
-    else:
-        local = torch.zeros((0, frames, 265), dtype=torch.float32, device=dev)
+    local = whole_body_local(body, face, mfcc[a:b], ids[a:b], wav[a:b], face_ids[a:b], mode=mode, seed=seed,
+                             clip_index0=a, batch_body=batch_body, batch_face=batch_face, stand=stand)
     return gather_sequences(local, n), (a, b)

@@ -33,3 +33,19 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def third_party_mfcc(x, sample_rate=22000, n_fft=2048, hop=734, n_mels=256, n_mfcc=64):
+    """MFCC assembled from INSTALLED third-party implementations of torchaudio's definitions (torchaudio itself is absent):
+    torch.stft (periodic Hann, center, reflect, power 2) -> transformers.audio_utils.mel_filter_bank (htk, norm None) ->
+    power_to_db(db_range=80, per clip) -> scipy DCT-II ortho.  x (N,) float32 -> (T, n_mfcc) float64."""
+    import torch
+    from scipy.fft import dct
+    from transformers import audio_utils as au
+    spec = torch.stft(torch.from_numpy(np.asarray(x, np.float32)), n_fft=n_fft, hop_length=hop, win_length=n_fft,
+                      window=torch.hann_window(n_fft, periodic=True), center=True, pad_mode="reflect", normalized=False,
+                      onesided=True, return_complex=True)
+    power = spec.abs().pow(2.0).T.numpy().astype(np.float64)
+    mel = power @ au.mel_filter_bank(n_fft // 2 + 1, n_mels, 0.0, float(sample_rate // 2), sample_rate, None, "htk")
+    db = au.power_to_db(mel, reference=1.0, min_value=1e-10, db_range=80.0)
+    return dct(db, type=2, norm="ortho", axis=1)[:, :n_mfcc]

@@ -255,6 +255,21 @@ def main():
         print("face_full: out", tuple(out.shape), "std", float(out.std()), "hidden std", float(hs.std()))
         save("face_full", wav=wav, ids=ids.numpy(), out=out.numpy(), hidden=hs.numpy(), generate_zero_id=gen.numpy())
 
+    # ---- 5b. the face generator at BASELINE length: two full 10 s clips (160 000 samples -> 499 conv frames -> 300 output frames)
+    if want("face_10s"):
+        fcfg = json.load(open(os.path.join(REF, "config/face.json")))
+        from trainer.config import Object
+        w = quiet(nets.s2g_face, argparse.Namespace(gpu="cpu", infer=True), Object(fcfg))
+        w.load_state_dict({"generator": T(synth.face_state_dict(seed=7))})
+        B, N = 2, 160000
+        wav = synth.wav16(33, B, N)                          # regenerated from the seed by the tests (not stored: 1.3 MB)
+        w.generator.eval()
+        with torch.no_grad():
+            ids = torch.zeros(B, 4); ids[0, 1] = 1.0
+            out = w.generator(torch.from_numpy(wav)[:, None, :], None, ids, time_steps=300)[0]
+        print("face_10s: out", tuple(out.shape), "std", float(out.std()))
+        save("face_10s", wav_seed=np.asarray([33, B, N]), ids=ids.numpy(), out=out.numpy())
+
     # ---- 6. output assembly: demo.py:207-229 (length alignment + concat) and lower_body.part2full ------------------
     if want("assemble_full"):
         from data_utils.lower_body import part2full

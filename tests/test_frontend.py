@@ -1,6 +1,9 @@
-"""Host front-end (numpy restatement of torchaudio Resample + MFCC).  PARITY UNPINNED against torchaudio itself (not
-installed anywhere we can run); checked here against an independent float64 evaluation of the same published formulae
-and closed-form cases."""
+"""Host front-end (numpy restatement of torchaudio Resample + MFCC).  torchaudio itself is not installed anywhere we can
+run, so the restatement is pinned stage by stage against the INSTALLED third-party implementations of the same
+definitions: the STFT / power stage against `torch.stft` (the function torchaudio.transforms.Spectrogram calls), the
+HTK mel filterbank and the dB / top_db stage against `transformers.audio_utils` (HF's port of the torchaudio / librosa
+definitions), the DCT-II table against `scipy.fft.dct`, and the whole MFCC against a pipeline assembled from those
+pieces.  The sinc-Hann resampler has no installed counterpart: checked on closed-form properties only (UNPINNED)."""
 import math
 import os
 
@@ -74,3 +77,52 @@ def test_reference_demo_wavs_give_the_documented_frame_counts():
     assert gap == 44000 // 734 + 1 and feat.shape[1] == 64
     w = fe.get_wav16(os.path.join(REF_AUDIO, "1st-page.wav"))
     assert w.ndim == 2 and w.shape[1] == 1 and np.abs(w).max() <= 1.0
+
+
+# ---- pins against installed third-party implementations -----------------------------------------------------------------
+def _wave(n=22000 * 3, sr=22000, seed=1):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / sr
+    return (0.25 * np.sin(2 * np.pi * 330 * t) * (1 + 0.4 * np.sin(2 * np.pi * 2 * t)) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+
+
+def _torch_stft_power(x, n_fft=2048, hop=734):
+    import torch
+    spec = torch.stft(torch.from_numpy(x), n_fft=n_fft, hop_length=hop, win_length=n_fft,
+                      window=torch.hann_window(n_fft, periodic=True), center=True, pad_mode="reflect", normalized=False,
+                      onesided=True, return_complex=True)                      # torchaudio.functional.spectrogram's call
+    return spec.abs().pow(2.0).T.numpy()                                        # (T, n_fft//2+1)
+
+
+@pytest.mark.parametrize("hop", [734, 1467])
+def test_stft_power_stage_pinned_to_torch_stft(hop):
+    x = _wave()
+    got = fe.power_spectrogram(x, 2048, hop)
+    ref = _torch_stft_power(x, 2048, hop)
+    assert got.shape == ref.shape == (len(x) // hop + 1, 1025)
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4 * float(ref.max()) * 1e-3)
+
+
+def test_mel_db_dct_tables_pinned_to_transformers_and_scipy():
+    from scipy.fft import dct
+    from transformers import audio_utils as au
+    fb = fe.melscale_fbanks(1025, 0.0, 11000.0, 256, 22000)
+    hf = au.mel_filter_bank(num_frequency_bins=1025, num_mel_filters=256, min_frequency=0.0, max_frequency=11000.0,
+                            sampling_rate=22000, norm=None, mel_scale="htk")
+    np.testing.assert_allclose(fb, hf, atol=1e-6, rtol=0)
+    d = fe.create_dct(64, 256)
+    np.testing.assert_allclose(d, dct(np.eye(256), type=2, norm="ortho", axis=0)[:64].T, atol=1e-6, rtol=0)
+
+
+def test_whole_mfcc_against_third_party_pipeline():
+    """torch.stft -> HF mel_filter_bank -> HF power_to_db(db_range=80) -> scipy DCT-II ortho, vs frontend.mfcc."""
+    from scipy.fft import dct
+    from transformers import audio_utils as au
+    x = _wave(22000 * 4, seed=2)
+    power = _torch_stft_power(x).astype(np.float64)
+    mel = power @ au.mel_filter_bank(1025, 256, 0.0, 11000.0, 22000, None, "htk")
+    db = au.power_to_db(mel, reference=1.0, min_value=1e-10, db_range=80.0)
+    ref = dct(db, type=2, norm="ortho", axis=1)[:, :64].T
+    got = fe.mfcc(x, 22000)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, atol=2e-2, rtol=1e-4)               # O(10..1000) coefficients, fp32 pipeline

@@ -284,6 +284,38 @@ def test_wrapper_body_pixel_e2e(hip, golden, tmp_path):
     assert float(sd["generator"]["layers.0.vert_stack.weight"][:, :, -1].abs().max()) == 0.0
 
 
+def test_wrapper_continuity_and_id_broadcast(hip, tmp_path):
+    """`infer_on_audio(continuity=True)` through the wrapper (`smplx_body_pixel.py:245-269,291-304`) against the oracle's
+    restatement of the same two-chunk procedure (greedy), `id=None` with B > 1 (one label broadcast over the batch, as
+    nn.Embedding does), and the IndexError for a label outside [0, 4)."""
+    from nets.init_model import init_model
+    args = argparse.Namespace(gpu=0, infer=True)
+    w = init_model("s2g_body_pixel", args, _config(tmp_path))
+    sd_p, sd_a = synth.pixelcnn_state_dict(seed=7), synth.audioencoder_state_dict(seed=7)
+    w.load_state_dict({"generator": synth.to_torch(sd_p), "audioencoder": synth.to_torch(sd_a)})
+    sd_b, sd_h = synth.vqvae_state_dict(seed=7, in_dim=39), synth.vqvae_state_dict(seed=7, in_dim=90, salt=1)
+    T = 88                                                     # 2 s head (60 frames -> 15 code rows) + 28 frames (7 rows)
+    feat = synth.mfcc_features(123, 1, T)[0]                   # (T, 64): what get_mfcc_sepa returns for a wav
+    out = w.infer_on_audio(feat, id=torch.tensor([2]).cuda(), fps=30, sr=22000, B=1, continuity=True, greedy=True)
+    gap = 1 + 44000 // 734
+    ref, ref_codes = O.body_pixel_infer_continuity(feat[None], gap, np.asarray([2]), sd_a, sd_p, sd_b, sd_h)
+    assert out.shape == ref.shape == (1, 4 * (15 + 7), 129)
+    np.testing.assert_allclose(out, ref, atol=1e-4, rtol=0)
+    # id=None, B=3: label 0 for every clip of the batch (the reference passes a (1,) tensor to nn.Embedding)
+    mf = synth.mfcc_features(124, 1, 40)[0]
+    o3 = w.infer_on_audio(mf, id=None, fps=30, B=3, greedy=True)
+    o1 = w.infer_on_audio(mf, id=torch.tensor([0]).cuda(), fps=30, B=1, greedy=True)
+    assert o3.shape == (3, 40, 129)
+    for b in range(3):
+        np.testing.assert_array_equal(o3[b], o1[0])
+    with pytest.raises(IndexError):
+        w.infer_on_audio(mf, id=torch.tensor([4]).cuda(), fps=30, B=1, greedy=True)
+    with pytest.raises(IndexError):
+        w.generate_batch(np.repeat(mf[None], 2, 0), np.asarray([0, -1]), mode=0)
+    with pytest.raises(ValueError):
+        w.generate_batch(np.repeat(mf[None], 3, 0), np.asarray([0, 1]), mode=0)
+
+
 def test_wrapper_body_vq_e2e(hip, golden, tmp_path):
     from nets.init_model import init_model
     g = golden("body_vq_e2e_full")
@@ -330,6 +362,33 @@ def test_full_size_properties(hip, tmp_path):
     np.testing.assert_array_equal(body.cpu().numpy(), p1[..., :39].cpu().numpy())
 
 
+def test_golden_clips_inside_baseline_batches(hip, golden, tmp_path):
+    """The two reference-golden clips (body_e2e_full, B=2) embedded at arbitrary slots of a BASELINE batch of 32 and of a
+    coalesced chain of 128 clips (4 batches in one launch sequence, 64 x 32 tiles): their codes must equal the golden
+    bit for bit and their poses stay within 1e-4 — the B=32 / B=128 results are pinned to the reference directly, not
+    only through self-consistency."""
+    from nets.init_model import init_model
+    from talkshow_amd import _lib
+    g = golden("body_e2e_full")
+    args = argparse.Namespace(gpu=0, infer=True)
+    w = init_model("s2g_body_pixel", args, _config(tmp_path))
+    w.load_state_dict({"generator": synth.to_torch(synth.pixelcnn_state_dict(seed=7)),
+                       "audioencoder": synth.to_torch(synth.audioencoder_state_dict(seed=7))})
+    for B, slots in ((32, (3, 29)), (128, (70, 127))):
+        mf, ids = synth.mfcc_features(90 + B, B, 300), synth.speaker_ids(B)
+        for k, s_ in enumerate(slots):
+            mf[s_], ids[s_] = g["mfcc"][k], g["ids"][k]
+        codes, poses = w.generate_batch(mf, ids, mode=_lib.TS_SAMPLE_GREEDY)
+        codes, poses = codes.cpu().numpy(), poses.cpu().numpy()
+        for k, s_ in enumerate(slots):
+            np.testing.assert_array_equal(codes[s_], g["codes"][k])
+            np.testing.assert_allclose(poses[s_], g["poses"][k], atol=1e-4, rtol=0)
+        if B == 128:     # coalescing is invisible: each 32-clip batch alone gives the same bits
+            c32, p32 = w.generate_batch(mf[64:96], ids[64:96], mode=_lib.TS_SAMPLE_GREEDY)
+            np.testing.assert_array_equal(c32.cpu().numpy(), codes[64:96])
+            np.testing.assert_array_equal(p32.cpu().numpy(), poses[64:96])
+
+
 # ----------------------------------------------------------------------------------------------- face generator
 def test_face_golden(hip, golden):
     """wav2vec2 encoder + LN conv heads vs the reference goldens (transformers module run by make_golden.py)."""
@@ -348,6 +407,27 @@ def test_face_golden(hip, golden):
     out2, none = m2(torch.from_numpy(g["wav"])[:, None, :], None, torch.from_numpy(g["ids"]), time_steps=frame)
     assert none is None
     np.testing.assert_array_equal(out2.cpu().numpy(), out.cpu().numpy())
+
+
+def test_face_10s_golden_inside_batch_64(hip, golden):
+    """BASELINE configs[2] shape: two reference-golden 10 s clips (160 000 samples) embedded in a batch of 64; their
+    rows must match the reference's output within 1e-4 whatever the rest of the batch holds."""
+    from talkshow_amd.modules import FaceGenerator
+    g = golden("face_10s")
+    seed, B0, N = [int(v) for v in g["wav_seed"]]
+    gw = synth.wav16(seed, B0, N)
+    m = FaceGenerator().cuda()
+    m.load_state_dict(synth.to_torch(synth.face_state_dict(seed=7)))
+    B = 64
+    wav = synth.wav16(500, B, N)
+    ids = np.eye(4, dtype=np.float32)[np.arange(B) % 4]
+    slots = (5, 63)
+    for k, s_ in enumerate(slots):
+        wav[s_], ids[s_] = gw[k], g["ids"][k]
+    out = m.run(wav, ids, 300).cpu().numpy()
+    assert out.shape == (B, 300, 103) and np.isfinite(out).all()
+    for k, s_ in enumerate(slots):
+        np.testing.assert_allclose(out[s_], g["out"][k], atol=1e-4, rtol=0)
 
 
 def test_wrapper_face(hip, golden, tmp_path):
@@ -476,7 +556,14 @@ def test_device_mfcc_vs_host_restatement(hip, tmp_path):
         np.testing.assert_allclose(dev[i], ref, atol=0.05, rtol=2e-4)
     # no resampling branch + the wav-file entry point used by infer_on_audio
     x = (0.3 * rng.standard_normal(22000 * 2)).astype(np.float32)
-    np.testing.assert_allclose(MFCC(22000, 22000, 30)(x)[0].cpu().numpy(), fe.mfcc(x, 22000).T, atol=0.05, rtol=2e-4)
+    got22 = MFCC(22000, 22000, 30)(x)[0].cpu().numpy()
+    np.testing.assert_allclose(got22, fe.mfcc(x, 22000).T, atol=0.05, rtol=2e-4)
+    # ... and against the pipeline assembled from installed third-party code (torch.stft, transformers.audio_utils, scipy):
+    # pins the device STFT-as-GEMM / mel / dB / DCT stages independently of this repo's own numpy twin
+    from conftest import third_party_mfcc
+    np.testing.assert_allclose(got22, third_party_mfcc(x), atol=0.05, rtol=2e-4)
+    x22 = fe.resample_sinc_hann(wav[None], 16000, 22000)[0]                  # resampler itself: unpinned, shared
+    np.testing.assert_allclose(dev[0], third_party_mfcc(x22), atol=0.05, rtol=2e-4)
     p = str(tmp_path / "a.wav")
     wavfile.write(p, 16000, np.stack([wav, wav2], 1))                       # stereo float wav
     a = fe.get_mfcc_ta(p, sr=22000, fps=30)                                    # device path
@@ -485,8 +572,9 @@ def test_device_mfcc_vs_host_restatement(hip, tmp_path):
     np.testing.assert_allclose(a, b, atol=0.05, rtol=2e-4)
 
 
-@pytest.mark.parametrize("env", [{"TS_SKINNY_V": "0"}, {"TS_NO_GRAPH": "1"}, {"TS_SKINNY_NT": "32"}],
-                         ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel"])
+@pytest.mark.parametrize("env", [{"TS_SKINNY_V": "0"}, {"TS_NO_GRAPH": "1"}, {"TS_SKINNY_NT": "32"},
+                                 {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"}],
+                         ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32"])
 def test_alternate_kernel_paths(hip, env):
     """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
     launches, the 32-column kernel).  The knobs are read once per process, so the golden-vector tests are re-run in a child

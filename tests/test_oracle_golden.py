@@ -71,6 +71,19 @@ def test_causality(golden):
     assert np.abs(base[:, :, i + 1] - pert[:, :, i + 1]).max() > 1e-3
 
 
+def test_continuity_prefix(golden):
+    """generate(pre_latents, pre_audio) (`gated_pixelcnn_v2.py:158-165`): greedy tail behind the golden head == the golden
+    tail (causality makes the prefix form equivalent to the single run)."""
+    g = golden("pix_small")
+    input_dim, dim, n_layers, n_cls, seed = [int(v) for v in g["cfg"]]
+    sd = synth.pixelcnn_state_dict(seed=seed, input_dim=input_dim, dim=dim, n_layers=n_layers, n_classes=n_cls)
+    aud = np.repeat(g["aud"].transpose(0, 2, 1)[:, :, :, None], 2, axis=3)
+    H0 = 4
+    tail = O.pixelcnn_generate(g["label"], aud[:, :, H0:], sd, n_layers, g["codes"].shape[1] - H0,
+                               pre_latents=g["codes"][:, :H0], pre_audio=aud[:, :, :H0])
+    np.testing.assert_array_equal(tail, g["codes"][:, H0:])
+
+
 def test_sampler_distribution():
     rng = np.random.default_rng(0)
     logits = rng.standard_normal((1, 16)).astype(np.float32) * 2
@@ -110,3 +123,34 @@ def test_assemble_full(golden):
             out = O.assemble_full(g["body"], g["face_" + tag], lower_pose_block(stand))
             assert out.shape == g[key + tag].shape
             assert np.array_equal(out, g[key + tag])
+
+
+# ---- the torch-CPU port used as bench.py's cpu_baseline (oracle/torch_port.py): pinned to the same goldens ----------
+def test_torch_port_vq_and_audio(golden):
+    import torch
+    from oracle import torch_port as TP
+    g = golden("vq_full_body")
+    sd = TP._t(_vq_sd(g["cfg"]))
+    with torch.no_grad():
+        z, e, idx = TP.vqvae_encode(torch.from_numpy(g["poses"]), sd)
+        recon = TP.vqvae_decode(idx, sd)
+    np.testing.assert_allclose(z.numpy(), g["z"], atol=TOL, rtol=0)
+    np.testing.assert_array_equal(idx.numpy(), g["idx"])
+    np.testing.assert_allclose(recon.numpy(), g["recon"], atol=TOL, rtol=0)
+    ga = golden("audioenc_full")
+    with torch.no_grad():
+        out = TP.audio_encoder(torch.from_numpy(ga["mfcc"]).transpose(1, 2), TP._t(synth.audioencoder_state_dict(seed=7)))
+    np.testing.assert_allclose(out.numpy(), ga["out"], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["pix_small", "pix_full"])
+def test_torch_port_pixelcnn_greedy(golden, name):
+    import torch
+    from oracle import torch_port as TP
+    g = golden(name)
+    input_dim, dim, n_layers, n_cls, seed = [int(v) for v in g["cfg"]]
+    sd = TP._t(synth.pixelcnn_state_dict(seed=seed, input_dim=input_dim, dim=dim, n_layers=n_layers, n_classes=n_cls))
+    aud = torch.from_numpy(g["aud"]).permute(0, 2, 1).unsqueeze(-1).repeat(1, 1, 1, 2)
+    with torch.no_grad():
+        codes = TP.pixelcnn_generate(torch.from_numpy(g["label"]), aud, sd, n_layers, g["codes"].shape[1])
+    np.testing.assert_array_equal(codes.numpy(), g["codes"])

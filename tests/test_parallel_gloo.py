@@ -41,7 +41,7 @@ def _worker(rank, world, port, n, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [8, 7])
+@pytest.mark.parametrize("n", [8, 7, 1])   # 1 clip on 2 ranks: rank 1 holds an empty shard
 def test_two_ranks_equal_one(tmp_path, n):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "all.pt")
