@@ -68,13 +68,17 @@ void ts_convnet_destroy(ts_convnet *net);
  * (two k4/s2/p1 convolutions: L -> floor(L/2)). */
 int ts_audioenc_forward(ts_convnet *net, const float *mfcc_dev, int B, int T, float *feat_dev, void *stream);
 
-/* ---- VQVAE(in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers, ·) — vqvae_1d.py:152 -- */
+/* ---- VQVAE(in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers, ·) — vqvae_1d.py:152 --
+ * num_embeddings == 0 builds the quantiser-free auto-encoder `vqvae_1d.AE` (vqvae_1d.py:211-235), the FGD feature
+ * extractor of nets/body_ae.py: same Encoder / Decoder, no vq_layer keys; its checkpoint's unused frame_enc / GRU
+ * entries (Decoder(ae=True), never touched by forward) are accepted and ignored. */
 int ts_vqvae_create(ts_ctx *ctx, const ts_tensor *sd, int n, int in_dim, int embedding_dim, int num_embeddings,
                     int num_hiddens, int num_residual_layers, ts_vqvae **out);
 void ts_vqvae_destroy(ts_vqvae *vq);
 /* VQVAE.encode (vqvae_1d.py:196-199) + VectorQuantizerEMA eval branch (vqvae_modules.py:274-286,311-323):
  * poses_dev (B,T,in_dim) -> z_dev (B,H,embedding_dim) [may be NULL], latents_dev (B,H) int64,
- * quantized_dev (B,H,embedding_dim) [may be NULL]. */
+ * quantized_dev (B,H,embedding_dim) [may be NULL].  For an auto-encoder handle (num_embeddings == 0) this is
+ * AE.encode (vqvae_1d.py:233-235): z_dev is required, the other two outputs must be NULL. */
 int ts_vqvae_encode(ts_vqvae *vq, const float *poses_dev, int B, int T, float *z_dev, int64_t *latents_dev,
                     float *quantized_dev, void *stream);
 /* VQVAE.decode(latents=...) (vqvae_1d.py:201-208): latents_dev (B,H) int64 -> recon written into
@@ -82,6 +86,10 @@ int ts_vqvae_encode(ts_vqvae *vq, const float *poses_dev, int B, int T, float *z
  * the two halves of one (B,4H,129) buffer — the torch.cat of smplx_body_pixel.py:285). */
 int ts_vqvae_decode(ts_vqvae *vq, const int64_t *latents_dev, int B, int H, float *out_dev, int out_ld,
                     int out_col0, void *stream);
+/* Decoder.forward on CONTINUOUS latents (AE.forward eval branch, vqvae_1d.py:225-229; also VQVAE.decode(e=...)):
+ * z_dev (B,H,embedding_dim) -> recon, same output addressing as ts_vqvae_decode. */
+int ts_vqvae_decode_z(ts_vqvae *vq, const float *z_dev, int B, int H, float *out_dev, int out_ld, int out_col0,
+                      void *stream);
 /* body + hand decode in lockstep into one (B,4H,body_dim+hand_dim) buffer (the two decode calls + torch.cat of
  * smplx_body_pixel.py:282-285). */
 int ts_vqvae_decode_pair(ts_vqvae *vq_body, ts_vqvae *vq_hand, const int64_t *lat_body_dev, const int64_t *lat_hand_dev,
@@ -204,6 +212,24 @@ int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int de
  * flops_out[3] (algorithmic 2*M*N*K of the GEMM launches; 0 for family 2). */
 int ts_prof_enable(ts_ctx *ctx, int on);
 int ts_prof_read(ts_ctx *ctx, double *ms_out, int64_t *launches_out, double *flops_out, int reset);
+
+/* ---- evaluation on the device --------------------------------------------------------------------
+ * The reference computes its metrics on the CPU after the hot path (scripts/test_body.py:113-194); these are the
+ * reductions behind them, float64 accumulation, deterministic (fixed-order partial sums, no float atomics).
+ * Outputs are device doubles. */
+/* evaluation/FGD.py:131-146 (np.mean / np.cov inputs of the Frechet distance): feat_dev (n,D) float32, D in {32,64,128}
+ * -> stats_dev[0..D) = sum over rows, stats_dev[D + i*D + j] = sum over rows of x_i x_j  (D + D*D doubles). */
+int ts_eval_feat_stats(ts_ctx *ctx, const float *feat_dev, int64_t n, int D, double *stats_dev, void *stream);
+/* evaluation/FGD.py:153-158 (feat_dist numerator): sum over all n elements of |a - b|. */
+int ts_eval_l1_total(ts_ctx *ctx, const float *a_dev, const float *b_dev, int64_t n, double *out_dev, void *stream);
+/* scripts/test_body.py:98-110 body_loss on joints: gt_dev (T,J,3), prs_dev (B,T,J,3) ->
+ * out3_dev = { sum_t sum_b sum_{j<J_lvd} | |v_pr| - |v_gt| | over t < T_lvd-1   (LVD numerator, metrics.py:73-84),
+ *              sum_{b,t,j} |gt - pr|_2                                           ("error" numerator),
+ *              sum_{t,j} | var_b(pr) |_2  (unbiased variance over the B samples) ("diverse" numerator) }. */
+int ts_eval_body_loss(ts_ctx *ctx, const float *gt_dev, const float *prs_dev, int B, int T, int J, int J_lvd, int T_lvd,
+                      double *out3_dev, void *stream);
+/* evaluation/metrics.py:96-109 diversity: kps_dev (bs, L) -> sum over pairs i<j of sum_k |kps_i[k] - kps_j[k]|. */
+int ts_eval_diversity(ts_ctx *ctx, const float *kps_dev, int bs, int64_t L, double *out_dev, void *stream);
 
 #ifdef __cplusplus
 }

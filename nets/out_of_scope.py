@@ -1,5 +1,5 @@
-"""Names the reference's `nets` package exports that the hot-path scope leaves out (evaluation AE,
-Habibie et al. baseline).  Constructing them says so instead of failing with an ImportError."""
+"""Names the reference's `nets` package exports that the hot-path scope leaves out (the Habibie et al.
+baseline).  Constructing them says so instead of failing with an ImportError."""
 
 
 class _OutOfScope:
@@ -9,10 +9,6 @@ class _OutOfScope:
         raise NotImplementedError(
             f"{self._what} is outside the speech->SMPL-X inference hot path this package implements "
             "(SURVEY.md §2/§8: evaluation / baseline component); use the reference implementation for it.")
-
-
-class s2g_body_ae(_OutOfScope):
-    _what = "s2g_body_ae (FGD feature-extractor auto-encoder, nets/body_ae.py)"
 
 
 class LS3DCG(_OutOfScope):

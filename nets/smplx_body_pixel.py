@@ -20,80 +20,55 @@ class TrainWrapper(TrainWrapperBaseClass):
     '''
 
     def __init__(self, args, config):
-        self.args = args
-        self.config = config
-        self.device = resolve_device(self.args.gpu)
-        self.global_step = 0
-
-        self.convert_to_6d = self.config.Data.pose.convert_to_6d
-        self.expression = self.config.Data.pose.expression
-        self.epoch = 0
+        model_cfg, pose_cfg = config.Model, config.Data.pose
+        self.args, self.config = args, config
+        self.device = resolve_device(args.gpu)
+        self.global_step = self.epoch = 0
+        self.convert_to_6d, self.expression = pose_cfg.convert_to_6d, pose_cfg.expression
+        if self.convert_to_6d:   # would be GatedPixelCNN(dim 512, 10 layers); no shipped config uses it
+            raise NotImplementedError("convert_to_6d=true is not used by any shipped config (SURVEY.md §2)")
         self.init_params()
         self.num_classes = 4
         self.audio = True
-        self.composition = self.config.Model.composition
-        self.bh_model = self.config.Model.bh_model
+        self.composition, self.bh_model = model_cfg.composition, model_cfg.bh_model
 
+        # the four networks of `smplx_body_pixel.py:46-57`, same hyper-parameters
         self.audioencoder = AudioEncoder(in_dim=64, num_hiddens=256, num_residual_layers=2,
                                          num_residual_hiddens=256).to(self.device)
-        if self.convert_to_6d:
-            dim, layer = 512, 10
-        else:
-            dim, layer = 256, 15
-        self.generator = pixelcnn(2048, dim, layer, self.num_classes, self.audio, self.bh_model).to(self.device)
-        self.g_body = s2g_body(self.each_dim[1], embedding_dim=64, num_embeddings=config.Model.code_num,
-                               num_hiddens=1024, num_residual_layers=2, num_residual_hiddens=512).to(self.device)
-        self.g_hand = s2g_body(self.each_dim[2], embedding_dim=64, num_embeddings=config.Model.code_num,
-                               num_hiddens=1024, num_residual_layers=2, num_residual_hiddens=512).to(self.device)
-
-        # smplx_body_pixel.py:59-62 — the VQ checkpoint is loaded in the constructor
-        model_path = self.config.Model.vq_path
-        model_ckpt = torch.load(model_path, map_location=torch.device('cpu'))
-        self.g_body.load_state_dict(model_ckpt['generator']['g_body'])
-        self.g_hand.load_state_dict(model_ckpt['generator']['g_hand'])
+        self.generator = pixelcnn(2048, 256, 15, self.num_classes, self.audio, self.bh_model).to(self.device)
+        vq_kw = dict(embedding_dim=64, num_embeddings=model_cfg.code_num, num_hiddens=1024, num_residual_layers=2,
+                     num_residual_hiddens=512)
+        self.g_body = s2g_body(self.each_dim[1], **vq_kw).to(self.device)
+        self.g_hand = s2g_body(self.each_dim[2], **vq_kw).to(self.device)
+        # ... and, as in the reference (`:59-62`), the VQ-VAE weights come from `Model.vq_path` right here
+        vq_ckpt = torch.load(model_cfg.vq_path, map_location='cpu')['generator']
+        self.g_body.load_state_dict(vq_ckpt['g_body'])
+        self.g_hand.load_state_dict(vq_ckpt['g_hand'])
 
         self.discriminator = None
-        if self.convert_to_6d:
-            raise NotImplementedError("convert_to_6d=true is not used by any shipped config (SURVEY.md §2)")
         self.c_index = c_index_3d
-
         super().__init__(args, config)
 
     def init_optimizer(self):
-        self.generator_optimizer = None
-        self.audioencoder_optimizer = None
-        self.discriminator_optimizer = None
+        self.generator_optimizer = self.audioencoder_optimizer = self.discriminator_optimizer = None
 
     def state_dict(self):
-        model_state = {
-            'generator': self.generator.state_dict(),
-            'generator_optim': None,
-            'audioencoder': self.audioencoder.state_dict() if self.audio else None,
-            'audioencoder_optim': None,
-            'discriminator': None,
-            'discriminator_optim': None,
-        }
-        return model_state
+        # the six entries of a reference checkpoint (`smplx_body_pixel.py:104-113`); optimiser slots stay empty here
+        out = dict.fromkeys(('generator', 'generator_optim', 'audioencoder', 'audioencoder_optim', 'discriminator',
+                             'discriminator_optim'))
+        out['generator'] = self.generator.state_dict()
+        out['audioencoder'] = self.audioencoder.state_dict() if self.audio else None
+        return out
 
     def load_state_dict(self, state_dict):
-        from collections import OrderedDict
-        new_state_dict = OrderedDict()  # strip `module.` (smplx_body_pixel.py:117-127)
-        for k, v in state_dict.items():
-            sub_dict = OrderedDict()
-            if v is not None and hasattr(v, 'items'):
-                for k1, v1 in v.items():
-                    name = k1.replace('module.', '') if isinstance(k1, str) else k1
-                    sub_dict[name] = v1
-                new_state_dict[k] = sub_dict
-            else:
-                new_state_dict[k] = v
-        state_dict = new_state_dict
-        if 'generator' in state_dict:
-            self.generator.load_state_dict(state_dict['generator'])
-        else:
-            self.generator.load_state_dict(state_dict)
-        if 'audioencoder' in state_dict and self.audioencoder is not None:
-            self.audioencoder.load_state_dict(state_dict['audioencoder'])
+        """Accepts what the reference accepts (`:115-142`): a checkpoint dict with 'generator' (+ 'audioencoder', optimiser
+        entries ignored) or a bare generator state_dict; DataParallel's `module.` prefixes are dropped."""
+        def unprefixed(sd):
+            return {(k.replace('module.', '') if isinstance(k, str) else k): v for k, v in sd.items()}
+        nested = {k: unprefixed(v) for k, v in state_dict.items() if hasattr(v, 'items')}
+        self.generator.load_state_dict(nested['generator'] if 'generator' in nested else unprefixed(state_dict))
+        if 'audioencoder' in nested and self.audioencoder is not None:
+            self.audioencoder.load_state_dict(nested['audioencoder'])
 
     # ---------------------------------------------------------------------------------------------------------
     def _decode_pair(self, latents):

@@ -12,28 +12,24 @@ from talkshow_amd.pose_index import c_index_3d
 
 class TrainWrapper(TrainWrapperBaseClass):
     def __init__(self, args, config):
-        self.args = args
-        self.config = config
-        self.device = resolve_device(self.args.gpu)
-        self.global_step = 0
-
-        self.convert_to_6d = self.config.Data.pose.convert_to_6d
-        self.expression = self.config.Data.pose.expression
-        self.epoch = 0
-        self.init_params()
-        self.num_classes = 4
-        self.composition = self.config.Model.composition
-        if self.composition:
-            self.g_body = s2g_body(self.each_dim[1], embedding_dim=64, num_embeddings=config.Model.code_num,
-                                   num_hiddens=1024, num_residual_layers=2, num_residual_hiddens=512).to(self.device)
-            self.g_hand = s2g_body(self.each_dim[2], embedding_dim=64, num_embeddings=config.Model.code_num,
-                                   num_hiddens=1024, num_residual_layers=2, num_residual_hiddens=512).to(self.device)
-        else:
-            self.g = s2g_body(self.each_dim[1] + self.each_dim[2], embedding_dim=64, num_embeddings=config.Model.code_num,
-                              num_hiddens=1024, num_residual_layers=2, num_residual_hiddens=512).to(self.device)
-        self.discriminator = None
+        model_cfg, pose_cfg = config.Model, config.Data.pose
+        self.args, self.config = args, config
+        self.device = resolve_device(args.gpu)
+        self.global_step = self.epoch = 0
+        self.convert_to_6d, self.expression = pose_cfg.convert_to_6d, pose_cfg.expression
         if self.convert_to_6d:
             raise NotImplementedError("convert_to_6d=true is not used by any shipped config (SURVEY.md §2)")
+        self.init_params()
+        self.num_classes = 4
+        self.composition = model_cfg.composition
+        vq_kw = dict(embedding_dim=64, num_embeddings=model_cfg.code_num, num_hiddens=1024, num_residual_layers=2,
+                     num_residual_hiddens=512)
+        if self.composition:     # separate body (39-d) and hand (90-d) VQ-VAEs, `smplx_body_vq.py:39-43`
+            self.g_body = s2g_body(self.each_dim[1], **vq_kw).to(self.device)
+            self.g_hand = s2g_body(self.each_dim[2], **vq_kw).to(self.device)
+        else:                    # one VQ-VAE over all 129 dims, `:45-46`
+            self.g = s2g_body(self.each_dim[1] + self.each_dim[2], **vq_kw).to(self.device)
+        self.discriminator = None
         self.c_index = c_index_3d
         super().__init__(args, config)
 
@@ -41,19 +37,20 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.g_body_optimizer = self.g_hand_optimizer = self.g_optimizer = None
         self.generator_optimizer = self.discriminator_optimizer = None
 
+    def _nets(self):
+        return {'g_body': self.g_body, 'g_hand': self.g_hand} if self.composition else {'g': self.g}
+
     def state_dict(self):
-        if self.composition:
-            return {'g_body': self.g_body.state_dict(), 'g_body_optim': None,
-                    'g_hand': self.g_hand.state_dict(), 'g_hand_optim': None,
-                    'discriminator': None, 'discriminator_optim': None}
-        return {'g': self.g.state_dict(), 'g_optim': None, 'discriminator': None, 'discriminator_optim': None}
+        # checkpoint layout of `smplx_body_vq.py:77-94`: one entry per network + empty optimiser / discriminator slots
+        out = {'discriminator': None, 'discriminator_optim': None}
+        for name, net in self._nets().items():
+            out[name] = net.state_dict()
+            out[name + '_optim'] = None
+        return out
 
     def load_state_dict(self, state_dict):
-        if self.composition:
-            self.g_body.load_state_dict(state_dict['g_body'])
-            self.g_hand.load_state_dict(state_dict['g_hand'])
-        else:
-            self.g.load_state_dict(state_dict['g'])
+        for name, net in self._nets().items():
+            net.load_state_dict(state_dict[name])
 
     def parameters(self):
         return self.g_body.parameters() if self.composition else self.g.parameters()
@@ -109,13 +106,13 @@ class TrainWrapper(TrainWrapperBaseClass):
             output = denormalize(output, data_mean, data_std)
 
         if smooth:
-            lamda = 0.8
-            smooth_f = 10
-            frame = 149
-            for i in range(smooth_f):
-                f = frame + i
-                l = lamda * (i + 1) / smooth_f
-                output[0, f] = (1 - l) * output[0, f - 1] + l * output[0, f]
+            # `smplx_body_vq.py:284-291`: frames 149..158 of clip 0 are blended towards their predecessor, the weight of
+            # the frame itself growing from 0.08 to 0.8 (a chunk seam at 150 frames)
+            first, count, lam = 149, 10, 0.8
+            for i in range(count):
+                t = first + i
+                keep = lam * (i + 1) / count
+                output[0, t] = (1 - keep) * output[0, t - 1] + keep * output[0, t]
 
         output = np.concatenate(output, axis=1)
         return output

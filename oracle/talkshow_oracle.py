@@ -178,6 +178,13 @@ def vqvae_forward(gt_poses, sd):
     return e, vq_decoder(e, sd), idx
 
 
+def ae_forward(gt_poses, sd):
+    """vqvae_1d.AE.forward eval branch / AE.encode (`vqvae_1d.py:225-235`): gt_poses (B,T,in_dim) ->
+    (z (B,64,T//4), x_recon (B,in_dim,4*(T//4))).  The FGD feature of `body_ae.extract` is z transposed (`body_ae.py:151-152`)."""
+    z = vq_encoder(np.ascontiguousarray(gt_poses.transpose(0, 2, 1)), sd)
+    return z, vq_decoder(z, sd)
+
+
 # ----------------------------------------------------------------------------------------------
 # nets/spg/gated_pixelcnn_v2.py
 # ----------------------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ SIGNATURES = {
     "ts_vqvae_destroy": (None, [_vp]),
     "ts_vqvae_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "ts_vqvae_decode": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "ts_vqvae_decode_z": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "ts_vqvae_decode_pair": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ts_vqvae_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
     "ts_pixelcnn_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
@@ -61,6 +62,10 @@ SIGNATURES = {
     "ts_op_linear": (_i, [_vp, _vp, _i, _i, _fp, _fp, _i, _i, _vp, _vp]),
     "ts_op_sample": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ts_debug_skinny_chain": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
+    "ts_eval_feat_stats": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "ts_eval_l1_total": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "ts_eval_body_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ts_eval_diversity": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
     "ts_prof_enable": (_i, [_vp, _i]),
     "ts_prof_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _i]),
 }

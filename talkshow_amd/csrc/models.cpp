@@ -498,6 +498,7 @@ struct ts_vqvae {
     ts_convnet enc;
     DevBuf codebook, code_sq;
     DevBuf aft_table;   // [ncode][hid] = aft_vq_conv(embedding row): Decoder's first layer as a gather table
+    ConvLayer aft;      // aft_vq_conv itself: the decoder's first layer on CONTINUOUS latents (vqvae_1d.AE, ncode == 0)
     Stack d1, d2, d3;
     ConvLayer up2, up3, project;
     struct Work {
@@ -534,6 +535,7 @@ int vq_encode_n(int n, ts_vqvae *const *vq, const float *const *poses, int poses
     {
         MiscScope ms(ctx, s);
         for (int i = 0; i < n; ++i) {
+            if (vq[i]->ncode == 0) continue;   // auto-encoder flavour (vqvae_1d.AE): no quantiser, z is the result
             TS_HIP(launch_vq_argmin(zp[i], vq[i]->emb, B * H, vq[i]->codebook.f(), vq[i]->code_sq.f(), vq[i]->ncode, vq[i]->emb,
                                     lat_out[i], 1, s));
             if (q_out && q_out[i])
@@ -553,9 +555,10 @@ int vq_encode_impl(ts_vqvae *vq, const float *poses, int poses_ld, int B, int T,
     return vq_encode_n(1, vp, pp, poses_ld, B, T, zp, lp, qp, s, Hout);
 }
 
-// n = 1 or 2 decoders in lockstep: aft_vq table gather -> stacks / up-convs -> project into out[.., col0_i .. col0_i+in_dim_i)
-int vq_decode_n(int n, ts_vqvae *const *vq, const int64_t *const *lat, int B, int H, float *out, int out_ld, const int *col0,
-                hipStream_t s) {
+// n = 1 or 2 decoders in lockstep: first layer (aft_vq table gather for codes, or aft_vq_conv on continuous latents z)
+// -> stacks / up-convs -> project into out[.., col0_i .. col0_i+in_dim_i)
+int vq_decode_n(int n, ts_vqvae *const *vq, const int64_t *const *lat, const float *const *z, int B, int H, float *out,
+                int out_ld, const int *col0, hipStream_t s) {
     ts_ctx *ctx = vq[0]->ctx;
     const int hid = vq[0]->hid;
     Pool *pool[2];
@@ -563,8 +566,14 @@ int vq_decode_n(int n, ts_vqvae *const *vq, const int64_t *const *lat, int B, in
         if (vq[i]->hid != hid) return fail("paired VQ-VAEs must have the same width");
         pool[i] = &vq[i]->work(s).pool;
         TS_TRY(pool[i]->ensure((size_t)B * H * hid));
-        MiscScope ms(ctx, s);
-        TS_HIP(launch_gather_rows(vq[i]->aft_table.f(), hid, vq[i]->ncode, lat[i], 1, B * H, hid, pool[i]->buf(0), hid, s));
+        if (z && z[i]) {
+            int tmp = 0;
+            TS_TRY(run_layer(ctx, vq[i]->aft, z[i], vq[i]->emb, B, H, nullptr, 0, pool[i]->buf(0), hid, 0, hid, s, &tmp));
+        } else {
+            if (vq[i]->ncode == 0) return fail("this network has no codebook (auto-encoder): decode continuous latents");
+            MiscScope ms(ctx, s);
+            TS_HIP(launch_gather_rows(vq[i]->aft_table.f(), hid, vq[i]->ncode, lat[i], 1, B * H, hid, pool[i]->buf(0), hid, s));
+        }
     }
     int cur = 0, o = 0, L = H;
     const ConvLayer *Lp[2];
@@ -598,7 +607,7 @@ int vq_decode_n(int n, ts_vqvae *const *vq, const int64_t *const *lat, int B, in
 int vq_decode_impl(ts_vqvae *vq, const int64_t *lat, int B, int H, float *out, int out_ld, int col0, hipStream_t s) {
     ts_vqvae *vp[1] = {vq};
     const int64_t *lp[1] = {lat};
-    return vq_decode_n(1, vp, lp, B, H, out, out_ld, &col0, s);
+    return vq_decode_n(1, vp, lp, nullptr, B, H, out, out_ld, &col0, s);
 }
 
 }  // namespace
@@ -687,18 +696,17 @@ int ts_vqvae_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int in_dim, int em
     TS_TRY(pack_trunk(ctx, sd, "encoder.", in_dim, hid, nres, &vq->enc));
     vq->enc.has_pre_vq = true;
     TS_TRY(pack_conv_layer(sd, "encoder.pre_vq_conv", "", "", 0, 1, hid, emb, 0, &vq->enc.pre_vq));
-    const float *cb = sd.get("vq_layer.embeddings", {ncode, emb});
-    if (!cb) return 1;
-    TS_TRY(vq->codebook.upload(cb, (size_t)ncode * emb * sizeof(float)));
-    TS_TRY(vq->code_sq.ensure((size_t)ncode * sizeof(float)));
-    TS_HIP(launch_row_sqnorm(vq->codebook.f(), ncode, emb, vq->code_sq.f(), 0));
-    // decoder
-    ConvLayer aft;
-    TS_TRY(pack_conv_layer(sd, "decoder.aft_vq_conv", "", "", 0, 1, emb, hid, 0, &aft));
-    TS_TRY(vq->aft_table.ensure((size_t)ncode * hid * sizeof(float)));
-    {   // aft_vq_conv applied to every codebook row once: Decoder.forward's first layer becomes a row gather
+    TS_TRY(pack_conv_layer(sd, "decoder.aft_vq_conv", "", "", 0, 1, emb, hid, 0, &vq->aft));
+    if (ncode > 0) {
+        const float *cb = sd.get("vq_layer.embeddings", {ncode, emb});
+        if (!cb) return 1;
+        TS_TRY(vq->codebook.upload(cb, (size_t)ncode * emb * sizeof(float)));
+        TS_TRY(vq->code_sq.ensure((size_t)ncode * sizeof(float)));
+        TS_HIP(launch_row_sqnorm(vq->codebook.f(), ncode, emb, vq->code_sq.f(), 0));
+        TS_TRY(vq->aft_table.ensure((size_t)ncode * hid * sizeof(float)));
+        // aft_vq_conv applied to every codebook row once: Decoder.forward's first layer becomes a row gather
         ConvParams p;
-        conv_layer_params(aft, vq->codebook.f(), emb, 1, ncode, nullptr, 0, vq->aft_table.f(), hid, 0, hid, &p);
+        conv_layer_params(vq->aft, vq->codebook.f(), emb, 1, ncode, nullptr, 0, vq->aft_table.f(), hid, 0, hid, &p);
         TS_HIP(launch_conv_gemm(p, 0, 0));
         TS_HIP(hipStreamSynchronize(0));
     }
@@ -716,7 +724,9 @@ int ts_vqvae_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int in_dim, int em
 void ts_vqvae_destroy(ts_vqvae *vq) { delete vq; }
 
 int ts_vqvae_encode(ts_vqvae *vq, const float *poses, int B, int T, float *z, int64_t *lat, float *q, void *stream) {
-    if (!vq || !poses || !lat) return fail("ts_vqvae_encode: null argument");
+    if (!vq || !poses) return fail("ts_vqvae_encode: null argument");
+    if (vq->ncode > 0 && !lat) return fail("ts_vqvae_encode: latents_dev is required for a network with a codebook");
+    if (vq->ncode == 0 && (!z || lat || q)) return fail("ts_vqvae_encode: an auto-encoder (num_embeddings = 0) produces z only");
     int H = 0;
     return vq_encode_impl(vq, poses, 0, B, T, z, lat, q, (hipStream_t)stream, &H);
 }
@@ -727,9 +737,19 @@ int ts_vqvae_decode(ts_vqvae *vq, const int64_t *lat, int B, int H, float *out, 
     return vq_decode_impl(vq, lat, B, H, out, out_ld, col0, (hipStream_t)stream);
 }
 
+int ts_vqvae_decode_z(ts_vqvae *vq, const float *z, int B, int H, float *out, int out_ld, int col0, void *stream) {
+    if (!vq || !z || !out) return fail("ts_vqvae_decode_z: null argument");
+    if (out_ld < col0 + vq->in_dim) return fail("ts_vqvae_decode_z: out_ld too small");
+    ts_vqvae *vp[1] = {vq};
+    const float *zp[1] = {z};
+    const int64_t *lp[1] = {nullptr};
+    return vq_decode_n(1, vp, lp, zp, B, H, out, out_ld, &col0, (hipStream_t)stream);
+}
+
 int ts_vqvae_forward(ts_vqvae *vq, const float *poses, int B, int T, int64_t *lat, float *out, int out_ld, int col0,
                      void *stream) {
     if (!vq || !poses || !out) return fail("ts_vqvae_forward: null argument");
+    if (vq->ncode == 0) return fail("ts_vqvae_forward: auto-encoder handle; use ts_vqvae_encode + ts_vqvae_decode_z");
     hipStream_t s = (hipStream_t)stream;
     int H = 0;
     int64_t *l = lat;
@@ -763,7 +783,7 @@ int ts_body_vq_infer(ts_vqvae *vb, ts_vqvae *vh, const float *poses, int B, int 
     if (recon) {
         const int col0[2] = {0, db};
         const int64_t *lc[2] = {lp[0], lp[1]};
-        TS_TRY(vq_decode_n(2, vqs, lc, B, H, recon, ld, col0, s));
+        TS_TRY(vq_decode_n(2, vqs, lc, nullptr, B, H, recon, ld, col0, s));
     }
     if (codes)   // codes (B,H,2): column k
         for (int k = 0; k < 2; ++k)
@@ -779,7 +799,7 @@ int ts_vqvae_decode_pair(ts_vqvae *vb, ts_vqvae *vh, const int64_t *lat_body, co
     ts_vqvae *vqs[2] = {vb, vh};
     const int64_t *lc[2] = {lat_body, lat_hand};
     const int col0[2] = {0, vb->in_dim};
-    return vq_decode_n(2, vqs, lc, B, H, out, vb->in_dim + vh->in_dim, col0, (hipStream_t)stream);
+    return vq_decode_n(2, vqs, lc, nullptr, B, H, out, vb->in_dim + vh->in_dim, col0, (hipStream_t)stream);
 }
 
 }  // extern "C"

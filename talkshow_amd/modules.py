@@ -235,6 +235,48 @@ class VQVAE(NativeModule):
         return q.transpose(1, 2), self.decode_nlc(lat).transpose(1, 2)
 
 
+class AE(VQVAE):
+    """`vqvae_1d.AE(in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers, ·)` (`vqvae_1d.py:211-235`):
+    Encoder + Decoder without a quantiser — the FGD feature extractor behind `nets.s2g_body_ae` (`body_ae.py:145-152`)."""
+
+    def __init__(self, in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers, num_residual_hiddens=None):
+        self.in_dim, self.embedding_dim, self.num_embeddings = in_dim, embedding_dim, 0
+        self.num_hiddens, self.nres = num_hiddens, num_residual_layers
+        NativeModule.__init__(self, synth.ae_state_dict(0, in_dim, embedding_dim, num_hiddens, num_residual_layers))
+
+    def encode_nlc(self, poses):
+        """poses (B,T,in_dim) -> z (B,T//4,embedding_dim), device tensor."""
+        poses = _dev_f32(poses, self._dev())
+        B, T, _ = poses.shape
+        if T < 4:
+            raise RuntimeError(f"sequence too short: {T} frames (need >= 4 for one latent row)")
+        z = torch.empty((B, T // 2 // 2, self.embedding_dim), dtype=torch.float32, device=poses.device)
+        _lib.check(_lib.load().ts_vqvae_encode(self.handle(), _lib.dptr(poses), B, T, _lib.dptr(z), None, None,
+                                               _lib.stream_ptr()))
+        return z
+
+    def decode_z_nlc(self, z):
+        z = _dev_f32(z, self._dev())
+        B, H, _ = z.shape
+        out = torch.empty((B, 4 * H, self.in_dim), dtype=torch.float32, device=z.device)
+        _lib.check(_lib.load().ts_vqvae_decode_z(self.handle(), _lib.dptr(z), B, H, _lib.dptr(out), self.in_dim, 0,
+                                                 _lib.stream_ptr()))
+        return out
+
+    # --- reference call shapes ---
+    def encode(self, gt_poses, id=None):
+        """`AE.encode` (`vqvae_1d.py:233-235`): gt_poses (B,T,in_dim) -> z (B,embedding_dim,T//4)."""
+        return self.encode_nlc(gt_poses).transpose(1, 2)
+
+    def decode(self, *a, **k):
+        raise NotImplementedError("AE has no code-index decode; use __call__ (encode -> decode of continuous latents)")
+
+    def __call__(self, gt_poses, id=None, pre_state=None):
+        """`AE.forward`, eval branch (`vqvae_1d.py:225-229`): (z (B,emb,H), x_recon (B,in_dim,T)); Decoder ignores pre_state."""
+        z = self.encode_nlc(gt_poses)
+        return z.transpose(1, 2), self.decode_z_nlc(z).transpose(1, 2)
+
+
 class GatedPixelCNN(NativeModule):
     """`gated_pixelcnn_v2.GatedPixelCNN(input_dim, dim, n_layers, n_classes, audio=True, bh_model=True)`."""
 

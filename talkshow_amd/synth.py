@@ -109,6 +109,32 @@ def vqvae_state_dict(seed=0, in_dim=39, embedding_dim=64, num_embeddings=2048, n
     return b.sd
 
 
+def ae_state_dict(seed=0, in_dim=129, embedding_dim=64, num_hiddens=1024, num_residual_layers=2, salt=0, in_scale=0.3,
+                  out_scale=0.3):
+    """`vqvae_1d.AE(in_dim, embedding_dim, 0, num_hiddens, num_residual_layers, ·)` (`vqvae_1d.py:211-235`): the VQ-VAE's
+    Encoder / Decoder without the quantiser, plus the `Decoder(ae=True)` extras (`frame_enc`, two GRUs, `:131-134`) that
+    sit in its checkpoints but are never used by `forward`."""
+    sd = vqvae_state_dict(seed, in_dim, embedding_dim, 8, num_hiddens, num_residual_layers, salt=700 + salt,
+                          in_scale=in_scale, out_scale=out_scale)
+    for k in [k for k in sd if k.startswith("vq_layer.")]:
+        del sd[k]
+    b = _Builder(seed, 777 + salt)
+    q = num_hiddens // 4
+    b.conv("decoder.frame_enc.proj", q, in_dim, 1, 1.0)
+    b.stack("decoder.frame_enc.enc", q, 2)
+    b.conv("decoder.frame_enc.proj_1", q, 4 * q, 1, 1.0)
+    b.conv("decoder.frame_enc.proj_2", 2 * q, 4 * q, 1, 1.0)
+    for name, h in (("gru_sl", num_hiddens // 2), ("gru_l", q)):
+        for part, shape in (("weight_ih_l0", (3 * h, h)), ("weight_hh_l0", (3 * h, h)), ("bias_ih_l0", (3 * h,)),
+                            ("bias_hh_l0", (3 * h,))):
+            b.normal(f"decoder.{name}.{part}", shape, 1.0 / np.sqrt(h))
+    # reference key order: decoder.* conv stacks, frame_enc, GRUs, then decoder.project last
+    proj = {k: sd.pop(k) for k in ("decoder.project.weight", "decoder.project.bias")}
+    sd.update(b.sd)
+    sd.update(proj)
+    return sd
+
+
 def pixelcnn_state_dict(seed=0, input_dim=2048, dim=256, n_layers=15, n_classes=4, aud_dim=256):
     """`GatedPixelCNN(input_dim, dim, n_layers, n_classes, audio=True, bh_model=True)` (`gated_pixelcnn_v2.py:90-128`)."""
     b = _Builder(seed, 303)

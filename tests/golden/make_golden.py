@@ -270,6 +270,78 @@ def main():
         print("face_10s: out", tuple(out.shape), "std", float(out.std()))
         save("face_10s", wav_seed=np.asarray([33, B, N]), ids=ids.numpy(), out=out.numpy())
 
+    # ---- 5c. FGD feature extractor: vqvae_1d.AE through the reference wrapper nets.s2g_body_ae (body_ae.py:145-152) -------
+    if want("ae_full"):
+        cfg = json.load(open(os.path.join(REF, "config/body_pixel.json")))
+        from trainer.config import Object
+        w = quiet(nets.s2g_body_ae, argparse.Namespace(gpu="cpu", infer=True), Object(cfg))
+        sd = synth.ae_state_dict(seed=7)
+        w.load_state_dict({"g": T(sd)})                      # strict: pins the key names / shapes of ae_state_dict
+        B, Tn = 2, 40
+        p129 = synth.gt_poses(51, B, Tn)
+        from data_utils.lower_body import c_index_3d
+        wide = np.zeros((B, Tn, 165), np.float32)
+        wide[:, :, c_index_3d] = p129
+        w.g.eval()
+        with torch.no_grad():
+            feat, x129 = w.extract(torch.from_numpy(wide))                   # 165-wide rows -> c_index gather -> encode
+            feat2, _ = w.extract(torch.from_numpy(p129))                     # already 129 wide
+            z, recon = w.g(gt_poses=torch.from_numpy(p129))                  # AE.forward, eval branch
+        assert torch.equal(feat, feat2) and torch.equal(x129, torch.from_numpy(p129))
+        print("ae_full: feat", tuple(feat.shape), "std", float(feat.std()), "recon std", float(recon.std()))
+        save("ae_full", poses129=p129, feat=feat.numpy(), z=z.numpy(), recon=recon.numpy())
+
+    # ---- 5d. evaluation metrics: the reference's own evaluation/FGD.py, evaluation/metrics.py and test_body.body_loss ------
+    if want("eval_metrics"):
+        import ast
+        from evaluation.FGD import EmbeddingSpaceEvaluator
+        from evaluation import metrics as RM
+        rng = np.random.default_rng(61)
+
+        class StubAE:                                         # extract() = identity on ready-made feature rows
+            def extract(self, x):
+                return x, x
+        ev = EmbeddingSpaceEvaluator(StubAE(), None, "cpu")
+        real, gen = [], []
+        for clip in range(5):
+            H = 20 + 3 * clip
+            r = (rng.standard_normal((1, H, 64)) * 0.5 + 0.1).astype(np.float32)
+            g_ = (r + 0.2 * rng.standard_normal((2, H, 64))).astype(np.float32)
+            ev.push_samples(torch.from_numpy(g_), torch.from_numpy(r))
+            real.append(r); gen.append(g_)
+        fgd, feat_dist = ev.get_scores()
+        # body_loss is defined inside scripts/test_body.py, which cannot be imported (CUDA, dataset, smplx): take the
+        # function's own source out of the file and run it with the reference's LVD
+        src = open(os.path.join(REF, "scripts/test_body.py")).read()
+        fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "body_loss"][0]
+        ns = {"LVD": RM.LVD, "torch": torch}
+        exec(compile(ast.Module([fn], []), "test_body.body_loss", "exec"), ns)
+        T_, J_ = 50, 55
+        gt_j = rng.standard_normal((T_, J_, 3)).astype(np.float32).cumsum(0) * 0.01
+        pr_j = (gt_j[None] + 0.05 * rng.standard_normal((3, T_, J_, 3))).astype(np.float32)
+        bl = ns["body_loss"](torch.from_numpy(gt_j), torch.from_numpy(pr_j))
+        kps = rng.standard_normal((4, 30, 129)).astype(np.float32)
+        div = RM.diversity(kps)
+        lvd_single = RM.LVD(torch.from_numpy(gt_j), torch.from_numpy(pr_j[0]))
+        # beat metrics: 2 clips of joints + audio onset times
+        for clip in range(2):
+            jt = (rng.standard_normal((60, 55, 3)) * 0.3).astype(np.float32)
+            ev.push_joints(torch.from_numpy(jt[None].copy()), torch.from_numpy(jt.copy() * 0.9))
+            ev.push_aud(torch.from_numpy(np.sort(rng.uniform(0.1, 1.9, 7)).reshape(-1, 1)))
+        joints_real = [j.numpy().copy() for j in ev.real_joints_list]
+        joints_gen = [j.numpy().copy() for j in ev.generated_joints_list]
+        beats = [a.numpy().copy() for a in ev.audio_beat_list]
+        maac = ev.get_MAAC().numpy()
+        bc = ev.get_BCscore()
+        print("eval_metrics: fgd", float(fgd), "feat_dist", float(feat_dist), "body_loss", {k: float(v) for k, v in bl.items()},
+              "diversity", float(div), "bc", float(bc))
+        save("eval_metrics", real=np.concatenate([r.reshape(-1) for r in real]), gen=np.concatenate([g_.reshape(-1) for g_ in gen]),
+             clip_rows=np.asarray([r.shape[1] for r in real]), fgd=np.float64(fgd), feat_dist=np.float64(feat_dist),
+             gt_joints=gt_j, pr_joints=pr_j, lvd=np.float64(bl["LVD"]), error=np.float64(bl["error"]),
+             diverse=np.float64(bl["diverse"]), lvd_single=np.float64(lvd_single), kps=kps, diversity=np.float64(div),
+             joints_real=np.stack(joints_real), joints_gen=np.stack(joints_gen), beats=np.stack(beats), maac=maac,
+             bc=np.float64(bc))
+
     # ---- 6. output assembly: demo.py:207-229 (length alignment + concat) and lower_body.part2full ------------------
     if want("assemble_full"):
         from data_utils.lower_body import part2full

@@ -333,6 +333,46 @@ def test_wrapper_body_vq_e2e(hip, golden, tmp_path):
     np.testing.assert_array_equal(codes.cpu().numpy(), g["codes"])
 
 
+def test_wrapper_body_vq_single_network(hip, tmp_path):
+    """`composition=false` (`smplx_body_vq.py:45-46,277`): ONE VQ-VAE over all 129 dims — small widths, vs the oracle."""
+    from nets.init_model import init_model
+    cfg = _config(tmp_path, "body_vq")
+    cfg.Model.composition = False
+    w = init_model("s2g_body_vq", argparse.Namespace(gpu=0, infer=True), cfg)
+    sd = synth.vqvae_state_dict(seed=11, in_dim=129)
+    w.load_state_dict({"g": synth.to_torch(sd)})
+    assert set(w.state_dict()) == {"g", "g_optim", "discriminator", "discriminator_optim"}
+    B, T = 2, 24
+    p129 = synth.gt_poses(23, B, T)
+    full = np.zeros((B, 165, T), np.float32)
+    full[:, w.c_index, :] = p129.transpose(0, 2, 1)
+    out = w.infer_on_audio(None, initial_pose=torch.from_numpy(full), fps=30)
+    _, recon, _ = O.vqvae_forward(p129, sd)                                     # (B,129,T)
+    ref = np.concatenate(list(recon.transpose(0, 2, 1)), axis=1)               # np.concatenate(output, axis=1)
+    assert out.shape == ref.shape == (T, B * 129)
+    np.testing.assert_allclose(out, ref, atol=1e-4, rtol=0)
+
+
+def test_wrapper_body_ae_extract(hip, golden, tmp_path):
+    """nets.init_model('s2g_body_ae') -> load_state_dict({'g': ...}) -> extract(): the FGD feature extractor
+    (`body_ae.py:145-152`) vs the golden produced by the reference wrapper; AE.forward's reconstruction too."""
+    from nets.init_model import init_model
+    g = golden("ae_full")
+    w = init_model("s2g_body_ae", argparse.Namespace(gpu=0, infer=True), _config(tmp_path))
+    w.load_state_dict({"g": synth.to_torch(synth.ae_state_dict(seed=7))})
+    B, T = g["poses129"].shape[:2]
+    wide = np.zeros((B, T, 165), np.float32)
+    wide[:, :, w.c_index] = g["poses129"]
+    feat, x129 = w.extract(torch.from_numpy(wide))
+    assert feat.shape == (B, T // 4, 64) and x129.shape == (B, T, 129)
+    np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], atol=2e-5, rtol=0)
+    np.testing.assert_array_equal(x129.cpu().numpy(), g["poses129"])
+    z, recon = w.g(torch.from_numpy(g["poses129"]))
+    np.testing.assert_allclose(z.cpu().numpy(), g["z"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(recon.cpu().numpy(), g["recon"], atol=1e-4, rtol=0)
+    assert len(w.state_dict()["g"]) == 210                                      # the reference AE's key count
+
+
 # ----------------------------------------------------------------------------------------------- full-size properties
 def test_full_size_properties(hip, tmp_path):
     """BASELINE batch (32 clips x 10 s): determinism, batch-composition independence, encode(decode) idempotence."""
@@ -630,3 +670,52 @@ def test_whole_body_sharded_single_rank(hip, tmp_path):
     face = m.run(wav, fid, 60).cpu().numpy()
     ref = O.assemble_full(poses, face, lower_pose_block(False))
     np.testing.assert_allclose(rows.cpu().numpy(), ref, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------- evaluation on the device
+def test_evaluation_reductions_vs_reference_values(hip, golden):
+    """ts_eval_* (csrc/eval.hip) through the drop-in `evaluation` package against values the reference's own
+    evaluation/FGD.py, evaluation/metrics.py and test_body.body_loss produced (golden `eval_metrics`)."""
+    from evaluation.FGD import EmbeddingSpaceEvaluator
+    from evaluation import metrics as M
+    from talkshow_amd import evaluation as E
+    g = golden("eval_metrics")
+
+    class StubAE:                                               # the golden was made on ready-made feature rows
+        def extract(self, x):
+            return x.cuda(), x
+    ev = EmbeddingSpaceEvaluator(StubAE(), None, "cuda")
+    at_r = at_g = 0
+    for H in g["clip_rows"]:
+        H = int(H)
+        r = g["real"][at_r:at_r + H * 64].reshape(1, H, 64); at_r += H * 64
+        q = g["gen"][at_g:at_g + 2 * H * 64].reshape(2, H, 64); at_g += 2 * H * 64
+        ev.push_samples(torch.from_numpy(q), torch.from_numpy(r))
+    fgd, feat_dist = ev.get_scores()
+    np.testing.assert_allclose(fgd, g["fgd"], rtol=1e-5)        # reference: float32 np.mean, float64 np.cov
+    np.testing.assert_allclose(feat_dist, g["feat_dist"], rtol=1e-6)
+    bl = E.body_loss(g["gt_joints"], g["pr_joints"])
+    for k, ref in (("LVD", "lvd"), ("error", "error"), ("diverse", "diverse")):
+        np.testing.assert_allclose(bl[k], g[ref], rtol=2e-5)    # reference: float32 torch arithmetic
+    np.testing.assert_allclose(M.LVD(torch.from_numpy(g["gt_joints"]), torch.from_numpy(g["pr_joints"][0])), g["lvd_single"], rtol=2e-5)
+    np.testing.assert_allclose(M.diversity(g["kps"]), g["diversity"], rtol=1e-5)
+    # run-to-run determinism of the two-stage reductions (no float atomics)
+    assert E.body_loss(g["gt_joints"], g["pr_joints"]) == bl and M.diversity(g["kps"]) == M.diversity(g["kps"])
+
+
+def test_feature_stats_large_and_ragged(hip):
+    """Running float64 moments over many pushes of ragged sizes == numpy float64 mean / cov of all rows together."""
+    from oracle import eval_oracle as EO
+    from talkshow_amd import evaluation as E
+    rng = np.random.default_rng(8)
+    st, rows = E.FeatureStats(64), []
+    for n in (1, 127, 128, 129, 5000, 33):
+        x = (rng.standard_normal((n, 64)) * rng.uniform(0.1, 3.0, 64) + rng.standard_normal(64)).astype(np.float32)
+        st.push(x)
+        rows.append(x)
+    allr = np.vstack(rows).astype(np.float64)
+    mu, sig = st.mean_cov()
+    np.testing.assert_allclose(mu, allr.mean(0), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(sig, np.cov(allr, rowvar=False), rtol=1e-8, atol=1e-10)
+    with pytest.raises(RuntimeError, match="32, 64 or 128"):
+        E.FeatureStats(48).push(np.zeros((4, 48), np.float32))

@@ -107,9 +107,29 @@ def test_body_vq_wrapper_surface(tmp_path):
 
 def test_out_of_scope_names_say_so():
     import nets
-    for cls in (nets.s2g_body_ae, nets.LS3DCG):
-        with pytest.raises(NotImplementedError):
-            cls(None, None)
+    with pytest.raises(NotImplementedError):
+        nets.LS3DCG(None, None)
+
+
+def test_body_ae_wrapper_surface(tmp_path):
+    """nets.s2g_body_ae (FGD feature extractor): constructor, checkpoint keys, buffers vs parameters, CPU device refusal."""
+    import argparse
+    import json
+    from nets.init_model import init_model
+    from talkshow_amd import synth
+    from talkshow_amd.config import Object
+    cfg = Object(json.load(open(os.path.join(REPO, "config", "body_pixel.json"))))
+    w = init_model("s2g_body_ae", argparse.Namespace(gpu="cpu", infer=True), cfg)
+    sd = synth.to_torch(synth.ae_state_dict(seed=2))
+    w.load_state_dict({"g": sd})
+    out = w.state_dict()
+    assert set(out) == {"g", "g_optim", "discriminator", "discriminator_optim"} and list(out["g"]) == list(sd)
+    assert w.each_dim == [0, 39, 90, 100] and w.full_dim == 129      # expression=true in the shipped config
+    n_params = sum(p.numel() for p in w.parameters())
+    n_buffers = sum(v.numel() for k, v in sd.items() if k.endswith(("running_mean", "running_var", "num_batches_tracked")))
+    assert n_params == sum(v.numel() for v in sd.values()) - n_buffers
+    with pytest.raises(RuntimeError, match="HIP device"):
+        w.extract(torch.zeros(1, 8, 129))
 
 
 def test_pose_index_matches_reference_layout():

@@ -114,6 +114,15 @@ def test_body_vq_e2e_full(golden):
     np.testing.assert_allclose(out, g["out"], atol=1e-4, rtol=0)
 
 
+def test_ae_feature_extractor(golden):
+    """vqvae_1d.AE behind nets.s2g_body_ae.extract (the FGD feature space): oracle vs the reference wrapper's output."""
+    g = golden("ae_full")
+    z, recon = O.ae_forward(g["poses129"], synth.ae_state_dict(seed=7))
+    np.testing.assert_allclose(z, g["z"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(z.transpose(0, 2, 1), g["feat"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(recon, g["recon"], atol=TOL, rtol=0)
+
+
 def test_assemble_full(golden):
     """demo.py:207-229 + part2full: jaw | body (aligned to the face length) | expression with the lower-body block inserted."""
     from talkshow_amd.pose_index import lower_pose_block
