@@ -213,6 +213,36 @@ int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int de
 int ts_prof_enable(ts_ctx *ctx, int on);
 int ts_prof_read(ts_ctx *ctx, double *ms_out, int64_t *launches_out, double *flops_out, int reset);
 
+/* stage 1 of ts_mfcc_forward alone (get_mfcc_sepa, data_utils/utils.py:234-263, resamples the whole clip and then takes
+ * the MFCC of two parts): wav_dev (B,N) at sr_in -> out_dev (B, ts_mfcc_resampled_len(m, N)) at sr_out. */
+long ts_mfcc_resampled_len(const ts_mfcc *m, long n_samples);
+int ts_mfcc_resample(ts_mfcc *m, const float *wav_dev, int B, long n_samples, float *out_dev, void *stream);
+/* librosa.load(path, sr=16000) of the face front-end (data_utils/utils.py:194; librosa ~= 0.9.2 -> resampy 'kaiser_best'):
+ * band-limited interpolation with a Kaiser-windowed sinc table (64 zero crossings, 512 samples per crossing, rolloff
+ * 0.9475937167399596, beta 14.769656459379492), output length ceil(N * sr_out / sr_in) (librosa's fix_length).
+ * wav_dev (B,N) mono -> out_dev (B, ts_resample_kaiser_len(N, sr_in, sr_out)).  Third-party arithmetic: PARITY UNPINNED. */
+long ts_resample_kaiser_len(long n_samples, int sr_in, int sr_out);
+int ts_resample_kaiser(ts_ctx *ctx, const float *wav_dev, int B, long n_samples, int sr_in, int sr_out, float *out_dev,
+                       void *stream);
+
+/* ---- streaming generation -----------------------------------------------------------------------
+ * Replaces the pre_latents / pre_audio prefix of GatedPixelCNN.generate (gated_pixelcnn_v2.py:158-165) and its caller
+ * (smplx_body_pixel.py:260-269,291-304), which re-run the whole prefix for every chunk: a session keeps the row cache
+ * (one previous row per layer, the layer-0 partial sums, the last code rows) on the device, so a step costs the same
+ * whatever the history length and the state is O(1) (the receptive field is 17 code rows).  A clip generated in chunks
+ * is bit-identical to the same clip generated by one ts_pixelcnn_generate call (greedy; and stochastic, since the
+ * Philox position of a code is its absolute (row, column)).
+ * label_dev (B,) int64 is fixed for the session; max_chunk_rows bounds Hc of every step (buffers are sized once). */
+typedef struct ts_pixelcnn_stream ts_pixelcnn_stream;
+int ts_pixelcnn_stream_open(ts_pixelcnn *pix, const int64_t *label_dev, int B, int max_chunk_rows, ts_pixelcnn_stream **out);
+/* aud_dev (B,Hc,aud_dim): audio-encoder rows of the next Hc code rows -> codes_dev (B,Hc,2) int64.  mode: GREEDY,
+ * UNIFORMS (uniforms_dev (B,Hc,2)) or PHILOX (seed, clip_index0 as in ts_pixelcnn_generate). */
+int ts_pixelcnn_stream_step(ts_pixelcnn_stream *st, const float *aud_dev, int Hc, int mode, const float *uniforms_dev,
+                            uint64_t seed, int64_t clip_index0, int64_t *codes_dev, void *stream);
+/* code rows generated so far */
+int64_t ts_pixelcnn_stream_rows(const ts_pixelcnn_stream *st);
+void ts_pixelcnn_stream_close(ts_pixelcnn_stream *st);
+
 /* ---- evaluation on the device --------------------------------------------------------------------
  * The reference computes its metrics on the CPU after the hot path (scripts/test_body.py:113-194); these are the
  * reductions behind them, float64 accumulation, deterministic (fixed-order partial sums, no float atomics).

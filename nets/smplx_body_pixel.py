@@ -163,17 +163,14 @@ class TrainWrapper(TrainWrapperBaseClass):
         with torch.no_grad():
             aud_feat = aud_feat.permute(0, 2, 1)                      # (B, T, 64)
             if continuity:
+                # the reference generates the first 2 s, then the rest behind the first part's codes and audio rows as a
+                # prefix it re-runs in full (`:260-269`); here the second part continues the first part's row cache
                 self.audioencoder.eval()
-                pre_pose = {'b': None, 'h': None}
-                pre_latents, pre_audio, body_0, hand_0 = self.infer(aud_feat[:, :gap], frame, id, B, pre_pose=pre_pose,
-                                                                    mode=mode, seed=seed)
-                pre_pose['b'] = body_0[:, :, -4:].transpose(1, 2)
-                pre_pose['h'] = hand_0[:, :, -4:].transpose(1, 2)
-                _, _, body_1, hand_1 = self.infer(aud_feat[:, gap:], frame, id, B, pre_latents, pre_audio, pre_pose,
-                                                  mode=mode, seed=seed + 1)
-                body = torch.cat([body_0, body_1], dim=2)
-                hand = torch.cat([hand_0, hand_1], dim=2)
-                pred_poses = torch.cat([body, hand], dim=1).transpose(1, 2).cpu().numpy()
+                session = self.open_stream(id, B, max_frames=max(gap, aud_feat.shape[1] - gap))
+                part0 = session.push(aud_feat[:, :gap], mode=mode, seed=seed)
+                part1 = session.push(aud_feat[:, gap:], mode=mode, seed=seed)
+                session.close()
+                pred_poses = torch.cat([part0, part1], dim=1).cpu().numpy()
             else:
                 self.audioencoder.eval()
                 _, poses = self.generate_batch(aud_feat, id, mode=mode, uniforms=uniforms, seed=seed)
@@ -182,8 +179,17 @@ class TrainWrapper(TrainWrapperBaseClass):
         output = pred_poses
         return output
 
+    def open_stream(self, id, B, max_frames):
+        """Long-audio / continuity generation: a session that is fed MFCC chunks and returns the poses of
+        each chunk, every chunk continuing the PixelCNN row cache of the ones before it (`ts_pixelcnn_stream_*`) — the
+        reference's `infer(..., pre_latents, pre_audio)` chain (`:291-304`) for any number of chunks, at a cost per chunk
+        that does not grow with the history.  As in the reference, each chunk goes through the audio encoder and the VQ
+        decoders on its own (their receptive fields are not carried across chunks)."""
+        return BodyStream(self, id, B, max_frames)
+
     def infer(self, aud_feat, frame, id, B, pre_latents=None, pre_audio=None, pre_pose=None, mode=None, seed=0):
-        """smplx_body_pixel.py:291-304 (continuity helper): returns latents, audio (B,256,H,2), body, hand (B,C,T)."""
+        """smplx_body_pixel.py:291-304 (continuity helper, reference call shape): returns latents, audio (B,256,H,2),
+        body, hand (B,C,T); `pre_latents` / `pre_audio` are re-run as a prefix exactly like the reference does."""
         if mode is None:
             mode = _lib.TS_SAMPLE_PHILOX
         rows = self.audioencoder.forward_nlc(aud_feat)                                    # (B,H,256)
@@ -200,3 +206,25 @@ class TrainWrapper(TrainWrapperBaseClass):
         TypeError because `decode` returns tuples; this one returns the tensor it meant to.)"""
         _, poses = self.generate_batch(torch.as_tensor(aud).permute(0, 2, 1), id)
         return poses
+
+
+class BodyStream:
+    """See `TrainWrapper.open_stream`.  `push(mfcc_chunk (B,T,64)) -> poses (B, 4*(T//4), 129)` device tensor."""
+
+    def __init__(self, wrapper, id, B, max_frames):
+        self.w, self.B = wrapper, int(B)
+        if id is None:
+            id = torch.tensor([0])
+        self.pix = wrapper.generator.open_stream(id, self.B, max(1, int(max_frames) // 4))
+
+    @property
+    def frames(self):
+        return 4 * self.pix.rows
+
+    def push(self, mfcc, mode=_lib.TS_SAMPLE_PHILOX, seed=0, clip_index0=0, uniforms=None):
+        rows = self.w.audioencoder.forward_nlc(mfcc)                      # (B, T//4, 256), this chunk alone
+        codes = self.pix.step(rows, mode=mode, uniforms=uniforms, seed=seed, clip_index0=clip_index0)
+        return self.w._decode_pair(codes)
+
+    def close(self):
+        self.pix.close()

@@ -46,6 +46,10 @@ SIGNATURES = {
     "ts_pixelcnn_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ts_pixelcnn_destroy": (None, [_vp]),
     "ts_pixelcnn_generate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ts_pixelcnn_stream_open": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "ts_pixelcnn_stream_step": (_i, [_vp, _vp, _i, _i, _vp, _u64, _i64, _vp, _vp]),
+    "ts_pixelcnn_stream_rows": (_i64, [_vp]),
+    "ts_pixelcnn_stream_close": (None, [_vp]),
     "ts_face_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, C.POINTER(_vp)]),
     "ts_face_destroy": (None, [_vp]),
     "ts_face_generate": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -53,6 +57,10 @@ SIGNATURES = {
     "ts_mfcc_destroy": (None, [_vp]),
     "ts_mfcc_num_frames": (_i, [_vp, C.c_long]),
     "ts_mfcc_forward": (_i, [_vp, _vp, _i, C.c_long, _vp, _vp]),
+    "ts_mfcc_resampled_len": (C.c_long, [_vp, C.c_long]),
+    "ts_mfcc_resample": (_i, [_vp, _vp, _i, C.c_long, _vp, _vp]),
+    "ts_resample_kaiser_len": (C.c_long, [C.c_long, _i, _i]),
+    "ts_resample_kaiser": (_i, [_vp, _vp, _i, C.c_long, _i, _i, _vp, _vp]),
     "ts_pixelcnn_graph_stats": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "ts_body_pixel_infer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _u64, _i64, _vp, _vp, _vp]),
     "ts_body_vq_infer": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -143,7 +143,8 @@ struct SampleParams {
     long u_stride;
     uint64_t seed;
     int64_t clip_index0;
-    const uint64_t *dyn;   // optional device words {seed, clip_index0} overriding the two fields above (graph replay)
+    const uint64_t *dyn;   // optional device words {seed, clip_index0, position base}: the first two override the fields above, the
+                           // third is added to `position` (graph replay: a captured chunk serves every chunk of a session)
     uint32_t position;     // Philox counter word: linear position (row*2 + col)
     int *tok32;            // token for clip b written to tok32[b * tok_stride]
     long tok_stride;

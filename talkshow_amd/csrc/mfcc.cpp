@@ -7,6 +7,7 @@
 // The STFT is a DFT-as-GEMM on conv_gemm_f32 (2048 x 2050 real matrix, [cos | -sin] interleaved): 1.26 GMAC per 10 s
 // clip, exact fp32 MFMA accumulation, no FFT library needed.
 #include <cmath>
+#include <mutex>
 
 #include "host_common.h"
 
@@ -17,6 +18,8 @@ hipError_t launch_resample_polyphase(const float *x, int B, int N, const float *
                                      float *out, int Nout, hipStream_t s);
 hipError_t launch_frame_window(const float *x, int B, int N, int T, int hop, int nfft, const float *win, float *frames,
                                hipStream_t s);
+hipError_t launch_resample_kaiser(const float *x, int B, int N, const float *win, const float *delta, int nwin, int num_table,
+                                  double ratio, float *out, int Nout, int ldo, hipStream_t s);
 hipError_t launch_power_spectrum(const float *spec, int lds_, int nbins, float *pw, int ldp, long rows, hipStream_t s);
 hipError_t launch_db_topdb(float *mel, int B, long per_clip, float top_db, hipStream_t s);
 }  // namespace ts
@@ -126,6 +129,100 @@ int ts_mfcc_create(ts_ctx *ctx, int sr_in, int sr_out, int fps, ts_mfcc **out) {
     return 0;
 }
 void ts_mfcc_destroy(ts_mfcc *m) { delete m; }
+
+// stage 1 of ts_mfcc_forward on its own (get_mfcc_sepa resamples the whole clip first, then takes the MFCC of two parts):
+// wav_dev (B,N) at sr_in -> out_dev (B, ts_mfcc_resampled_len(m, N)) at sr_out
+long ts_mfcc_resampled_len(const ts_mfcc *m, long N) { return m ? m->resampled_len(N) : -1; }
+int ts_mfcc_resample(ts_mfcc *m, const float *wav, int B, long N, float *out, void *stream) {
+    if (!m || !wav || !out) return fail("ts_mfcc_resample: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    MiscScope ms(m->ctx, s);
+    if (m->sr_in == m->sr_out) {
+        TS_HIP(hipMemcpyAsync(out, wav, (size_t)B * N * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    TS_HIP(launch_resample_polyphase(wav, B, (int)N, m->rs_kern.f(), m->norig, m->nnew, m->width, m->kw, out,
+                                     (int)m->resampled_len(N), s));
+    return 0;
+}
+
+// ---- librosa.load(sr=16000)'s resampler (face path, data_utils/utils.py:194): resampy 'kaiser_best' ---------------------
+namespace {
+struct KaiserTable {
+    DevBuf win, delta;
+    int nwin = 0, num_table = 512;
+};
+// half of a sinc windowed by a Kaiser window: 64 zero crossings, 512 samples per crossing (resampy's published
+// 'kaiser_best' design: rolloff 0.9475937167399596, beta 14.769656459379492)
+int kaiser_table(int device, const KaiserTable **out) {
+    static std::mutex mu;
+    static std::map<int, std::unique_ptr<KaiserTable>> tabs;
+    std::lock_guard<std::mutex> g(mu);
+    auto &t = tabs[device];
+    if (!t) {
+        const int num_zeros = 64, precision = 9, num_bits = 1 << precision, n = num_bits * num_zeros;
+        const double rolloff = 0.9475937167399596, beta = 14.769656459379492, PI = 3.14159265358979323846;
+        auto i0 = [](double x) {   // modified Bessel function of the first kind, order 0 (power series)
+            double sum = 1.0, term = 1.0;
+            for (int k = 1; k < 500; ++k) {
+                term *= (x / (2.0 * k)) * (x / (2.0 * k));
+                sum += term;
+                if (term < 1e-18 * sum) break;
+            }
+            return sum;
+        };
+        std::vector<float> win(n + 1), delta(n + 1, 0.f);
+        const int Mw = 2 * n + 1;   // the full symmetric Kaiser window; its right half [n:] tapers the sinc
+        for (int i = 0; i <= n; ++i) {
+            const double tpos = (double)num_zeros * i / n;                  // np.linspace(0, num_zeros, n + 1)
+            const double a = rolloff * tpos * PI;
+            const double sinc = a == 0.0 ? 1.0 : std::sin(a) / a;
+            const double m = (double)(n + i) - (Mw - 1) / 2.0;            // scipy.signal.kaiser(M, beta)[n + i]
+            const double r = 2.0 * m / (Mw - 1);
+            const double taper = i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / i0(beta);
+            win[i] = (float)(taper * rolloff * sinc);
+        }
+        for (int i = 0; i < n; ++i) delta[i] = win[i + 1] - win[i];
+        std::unique_ptr<KaiserTable> k(new KaiserTable());
+        k->nwin = n + 1;
+        k->num_table = num_bits;
+        TS_TRY(k->win.upload(win.data(), win.size() * sizeof(float)));
+        TS_TRY(k->delta.upload(delta.data(), delta.size() * sizeof(float)));
+        t = std::move(k);
+    }
+    *out = t.get();
+    return 0;
+}
+}  // namespace
+
+// output length of librosa.resample(fix=True): ceil(N * sr_out / sr_in); resampy itself produces int(N * ratio) samples and
+// librosa.util.fix_length pads the (at most one) missing sample with zero
+long ts_resample_kaiser_len(long N, int sr_in, int sr_out) {
+    if (N < 0 || sr_in < 1 || sr_out < 1) return -1;
+    return (long)std::ceil((double)N * (double)sr_out / (double)sr_in);
+}
+int ts_resample_kaiser(ts_ctx *ctx, const float *wav, int B, long N, int sr_in, int sr_out, float *out, void *stream) {
+    if (!ctx || !wav || !out) return fail("ts_resample_kaiser: null argument");
+    if (B < 1 || N < 1 || sr_in < 1 || sr_out < 1) return fail("ts_resample_kaiser: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const long Nfix = ts_resample_kaiser_len(N, sr_in, sr_out);
+    MiscScope ms(ctx, s);
+    if (sr_in == sr_out) {
+        TS_HIP(hipMemcpyAsync(out, wav, (size_t)B * N * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    const KaiserTable *kt = nullptr;
+    TS_TRY(kaiser_table(ctx->device, &kt));
+    const double ratio = (double)sr_out / (double)sr_in;
+    const long Nres = (long)((double)N * ratio);          // int(shape * sample_ratio)
+    if (Nres < 1) return fail("ts_resample_kaiser: input too short for this rate change");
+    if (Nres < Nfix) TS_HIP(hipMemsetAsync(out, 0, (size_t)B * Nfix * sizeof(float), s));
+    // rows of Nfix samples; the (at most one) sample beyond Nres stays zero (fix_length)
+    const hipError_t e = launch_resample_kaiser(wav, B, (int)N, kt->win.f(), kt->delta.f(), kt->nwin, kt->num_table, ratio, out,
+                                                (int)Nres, (int)Nfix, s);
+    TS_HIP(e);
+    return 0;
+}
 
 // number of MFCC frames for N input samples: T = floor(N_resampled / hop) + 1 (center=True)
 int ts_mfcc_num_frames(const ts_mfcc *m, long N) { return m ? (int)(m->resampled_len(N) / m->hop) + 1 : -1; }

@@ -32,6 +32,52 @@ hipError_t launch_resample_polyphase(const float *x, int B, int N, const float *
     return hipGetLastError();
 }
 
+// Band-limited interpolation with a table-driven Kaiser-windowed sinc (J. O. Smith's algorithm as published in resampy,
+// the resampler behind librosa.load(sr=...) in the reference's pinned librosa 0.9.2: data_utils/utils.py:194).
+// win[0..nwin) is the right half of the filter sampled `num_table` times per zero crossing, delta[i] = win[i+1]-win[i].
+// Output sample t sits at input time t / ratio; left wing walks x[n], x[n-1], ..., right wing x[n+1], x[n+2], ...
+// One thread per output sample; the two table taps of a weight are adjacent floats.
+__global__ void resample_kaiser_kernel(const float *__restrict__ x, int N, const float *__restrict__ win,
+                                       const float *__restrict__ delta, int nwin, int num_table, double ratio,
+                                       float *__restrict__ out, int Nout, int ldo) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Nout) return;
+    const float *xb = x + (long)b * N;
+    const double scale = ratio < 1.0 ? ratio : 1.0;
+    const int index_step = (int)(scale * num_table);
+    const double time_register = (double)t / ratio;
+    const int n = (int)time_register;
+    double frac = scale * (time_register - n);
+    double index_frac = frac * num_table;
+    int offset = (int)index_frac;
+    double eta = index_frac - offset;
+    int i_max = (nwin - offset) / index_step;
+    i_max = i_max < n + 1 ? i_max : n + 1;
+    double acc = 0.0;
+    for (int i = 0; i < i_max; ++i) {
+        const int k = offset + i * index_step;
+        acc += ((double)win[k] + eta * (double)delta[k]) * (double)xb[n - i];
+    }
+    frac = scale - frac;
+    index_frac = frac * num_table;
+    offset = (int)index_frac;
+    eta = index_frac - offset;
+    int k_max = (nwin - offset) / index_step;
+    k_max = k_max < N - n - 1 ? k_max : N - n - 1;
+    for (int k2 = 0; k2 < k_max; ++k2) {
+        const int k = offset + k2 * index_step;
+        acc += ((double)win[k] + eta * (double)delta[k]) * (double)xb[n + k2 + 1];
+    }
+    out[(long)b * ldo + t] = (float)(acc * scale);   // resampy scales the filter by the ratio when decimating (unit DC gain)
+}
+hipError_t launch_resample_kaiser(const float *x, int B, int N, const float *win, const float *delta, int nwin, int num_table,
+                                  double ratio, float *out, int Nout, int ldo, hipStream_t s) {
+    hipLaunchKernelGGL(resample_kaiser_kernel, dim3((Nout + 255) / 256, B), dim3(256), 0, s, x, N, win, delta, nwin, num_table,
+                       ratio, out, Nout, ldo);
+    return hipGetLastError();
+}
+
 // frames[(b*T + t)][n] = w[n] * x_b[reflect(t*hop + n - n_fft/2)]
 __global__ void frame_window_kernel(const float *__restrict__ x, int N, int T, int hop, int nfft, const float *__restrict__ win,
                                     float *__restrict__ frames) {

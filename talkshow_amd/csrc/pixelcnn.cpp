@@ -15,10 +15,12 @@
 // Launch plan of row r (every entry is ONE skinny_gemm launch over all B clips; "|" separates independent problems that
 // share a launch, blockIdx.z):
 //   V0        v0.gate | v0.Q1 | v0.Q0                     gate: OV0 = gate(W2.E[r-1] + Q1[r] + Q0[r] + b + c0)
-//   V1        fuse_v | v2h_0                              XV_1[r] = fusion_v[:, :D].OV0 + AEV[r] ; V2H_0 = v2h(h_vert_0)
-//   V2        v1.gate | v1.P
-//   V_{l+1}   v_l.gate | v_l.P | v2h_{l-1}                l = 2..NL-1
-//   V_{NL+1}  v2h_{NL-1}
+//   V1        v1.gate | v1.P | v2h_0                      layer 1 reads OV0 directly: fusion_v[:, :D] (gated_pixelcnn_v2.py:137-144)
+//                                                         is composed into its two tap matrices on the host, the audio half
+//                                                         of the fusion becomes two per-row additive terms precomputed for
+//                                                         all rows (XV_1 is never materialised)
+//   V_l       v_l.gate | v_l.P | v2h_{l-1}                l = 2..NL-1
+//   V_NL      v2h_{NL-1}
 //   column j: hg_0, S_1 .. S_{NL-1}, head1', head2, sample
 //
 // Horizontal chain, one launch per layer.  In the reference a layer is gate(horiz_stack(x_h) + ...) followed by
@@ -48,6 +50,8 @@ struct ts_pixelcnn {
     std::vector<std::unique_ptr<DevBuf>> bv;                 // [2*2D] (duplicated per column)
     std::vector<std::unique_ptr<DevBuf>> wv2h, bv2h, wh, bh, cls, wr, br;
     DevBuf fva, fha;                                         // fusion_{v,h}[:, :D]  [D][D]
+    DevBuf wv1c, wv1p;                                       // layer 1 vertical taps with fusion_v[:, :D] composed in  [4D][2D]
+    ConvLayer aud_v1c, aud_v1p;                              // the same taps applied to the audio half of the fusion   [4D][D]
     ConvLayer aud_embed, aud_fv, aud_fh;                     // embedding_aud ; fusion_{v,h}[:, D:] (+ fusion bias)
     DevBuf w1, b1, w2, b2;                                   // output_conv
     // composed horizontal maps (see the header): per layer l >= 1
@@ -61,11 +65,11 @@ struct ts_pixelcnn {
     // batches can be in flight on different streams against the single weight copy above.
     struct Work {
         int capB = 0, capH = 0;
-        DevBuf aud_all, AE, AEV, AEH, AEH1, tok32, CR, XV, OV0, OVlast, HV, V2H, P, Q1, Q0, XH, G, T0, Y, LG, tfcodes;
+        DevBuf aud_all, AE, AEV, AEH, AEH1, AV1C, AV1P, tok32, CR, XV, OV0, OVlast, HV, V2H, P, Q1, Q0, XH, G, T0, Y, LG, tfcodes;
         // every pointer inside the captured kernels is one of the buffers above or the staging buffers below, so a graph
         // is valid for any caller pointers; key = (B, H, H0, mode)
         DevBuf codes_int, unif_int, dyn;
-        uint64_t dyn_host[16][2] = {};   // ring of sources for the async H2D copy of {seed, clip0}: must outlive the call
+        uint64_t dyn_host[16][3] = {};   // ring of sources for the async H2D copy of {seed, clip0, position base}: must outlive the call
         unsigned dyn_slot = 0;
         hipStream_t cap_stream = nullptr;
         std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
@@ -79,12 +83,19 @@ struct ts_pixelcnn {
             if (cap_stream) (void)hipStreamDestroy(cap_stream);
         }
     };
-    std::map<hipStream_t, std::unique_ptr<Work>> works;
-    Work &work(hipStream_t s) {
-        auto &w = works[s];
-        if (!w) w.reset(new Work());
-        return *w;
-    }
+    StreamWorks<Work> works;
+    Work &work(hipStream_t s) { return works.get(s); }
+};
+
+// f3: a generation session whose row cache (one previous row per layer + the layer-0 partial sums + the last code rows)
+// persists across calls — O(1) state for any history length (the receptive field is 17 code rows)
+struct ts_pixelcnn_stream {
+    ts_pixelcnn *p = nullptr;
+    int B = 0;
+    long rows = 0;              // code rows generated so far = absolute index of the next row
+    int max_rows = 0;           // largest chunk a step may bring (buffers are sized once, at open)
+    ts_pixelcnn::Work w;
+    DevBuf label;
 };
 
 namespace {
@@ -116,18 +127,22 @@ int ensure_work(ts_pixelcnn *p, ts_pixelcnn::Work *w, int B, int Htot) {
     TS_TRY(w->G.ensure((size_t)2 * cb * D * f));
     TS_TRY(w->T0.ensure(NL * cb * 2 * D * f));
     TS_TRY(w->AEH1.ensure((size_t)cb * ch * 2 * D * f));
+    TS_TRY(w->AV1C.ensure((size_t)cb * ch * 4 * D * f));
+    TS_TRY(w->AV1P.ensure((size_t)cb * ch * 4 * D * f));
     TS_TRY(w->Y.ensure((size_t)cb * p->HID * f));
     TS_TRY(w->LG.ensure((size_t)cb * p->V * f));
     TS_TRY(w->tfcodes.ensure((size_t)cb * ch * 2 * sizeof(int64_t)));
     TS_TRY(w->codes_int.ensure((size_t)cb * ch * 2 * sizeof(int64_t)));
     TS_TRY(w->unif_int.ensure((size_t)cb * ch * 2 * sizeof(float)));
-    TS_TRY(w->dyn.ensure(2 * sizeof(uint64_t)));
+    TS_TRY(w->dyn.ensure(3 * sizeof(uint64_t)));
     w->drop_graphs();   // buffers moved: captured pointers are stale
     w->capB = cb;
     w->capH = ch;
     return 0;
 }
 
+// Rows are ABSOLUTE indices of the session / call.  One-shot call: rows 0..Htot-1, the first H0 of them a known prefix.
+// Streaming step: rows r0..r0+Hc-1 behind a row cache left by the previous steps.
 struct RunCfg {
     int B, H, H0, Htot, mode;
     const float *uniforms;
@@ -137,7 +152,18 @@ struct RunCfg {
     float *logits;         // (B,H,2,V) or null
     const uint64_t *dyn;   // device {seed, clip0} (graph replay) or null
     ts_pixelcnn::Work *w;
+    int R;                 // rows of the token ring tok32[B][R][2]: row rr lives at rr % R (one-shot: R = Htot, no wrap)
+    int aud_r0, aud_rows;  // the audio-term buffers AEV / AEH / AEH1 hold rows [aud_r0, aud_r0 + aud_rows)
+    int out_r0;            // first row written to `codes` / `logits` / read from `uniforms` (those arrays hold H rows)
+    int pos_r0;            // Philox position of row r, column j = pos_base + (r - pos_r0) * 2 + j
+    long pos_base;         // (added on the device from a dynamic word when a captured graph is replayed)
+    int last_row;          // rows >= last_row are never generated: look-ahead partial sums for them are skipped
 };
+inline RunCfg one_shot_cfg(int B, int H, int H0, int mode, const float *uniforms, uint64_t seed, int64_t clip0, int64_t *codes,
+                           float *logits, ts_pixelcnn::Work *w) {
+    const int Htot = H0 + H;
+    return RunCfg{B, H, H0, Htot, mode, uniforms, seed, clip0, codes, logits, nullptr, w, Htot, 0, Htot, H0, H0, 0, Htot};
+}
 
 SkinnyParams base_params(int M, int N, int epi) {
     SkinnyParams q;
@@ -185,7 +211,7 @@ int launch_slot(ts_ctx *ctx, const Slot &a, const Slot *b, hipStream_t s) {
 
 // vertical stack + v->h projections of row r as NL+2 launch slots
 void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &out) {
-    const int B = c.B, D = p->D, NL = p->NL, Htot = c.Htot;
+    const int B = c.B, D = p->D, NL = p->NL, R = c.R;
     ts_pixelcnn::Work *w = c.w;
     const int *tok = w->tok32.i();
     auto XV = [&](int l, int par) { return w->XV.f() + ((size_t)(l * 2 + par) * B) * 2 * D; };
@@ -206,7 +232,7 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
         q.pre_stride = 4 * D;
     };
     auto emb_row = [&](SkinnyParams &q, int rr) {   // embeddings of both codes of row rr >= 0
-        for (int col = 0; col < 2; ++col) add_gather(q, p->emb.f(), D, tok + (size_t)rr * 2 + col, (long)Htot * 2, D);
+        for (int col = 0; col < 2; ++col) add_gather(q, p->emb.f(), D, tok + (size_t)(rr % R) * 2 + col, (long)R * 2, D);
     };
     auto make_v2h = [&](int l) {   // vert_to_horiz on the pre-gate activations, both columns
         SkinnyParams v = base_params(2 * B, 2 * D, EPI_LINEAR);
@@ -239,7 +265,7 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
         s.add(g);
         for (int t = 1; t >= 0 && r >= 1; --t) {   // row r-1's codes as seen from row r+1 (kernel row 1) and r+2 (kernel row 0)
             const int target = r + (2 - t);
-            if (target >= Htot) continue;
+            if (target >= c.last_row) continue;
             SkinnyParams q = base_params(B, 4 * D, EPI_LINEAR);
             emb_row(q, r - 1);
             q.W = p->wvt[0][t]->f();
@@ -256,45 +282,42 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
         out.push_back(s);
         return;
     }
-    {   // V1: audio fusion in front of layer 1 (gated_pixelcnn_v2.py:137-144) | v2h_0
+    for (int l = 1; l < NL; ++l) {   // V_l: v_l.gate | v_l.P | v2h_{l-1}
         Slot s;
-        SkinnyParams f = base_params(2 * B, D, EPI_LINEAR);
-        add_dense(f, w->OV0.f(), D, 0, D);
-        f.W = p->fva.f();
-        f.ldw = D;
-        f.add1 = w->AEV.f() + (size_t)r * D;
-        f.add1_stride = (long)Htot * D;
-        f.add1_shift = 1;
-        f.out = XV(1, r & 1);
-        f.out_stride = D;
-        s.add(f);
-        s.add(make_v2h(0));
-        out.push_back(s);
-    }
-    for (int l = 1; l < NL; ++l) {   // V_{l+1}: v_l.gate | v_l.P | v2h_{l-1}
-        Slot s;
+        // layer 1 reads the gate output of layer 0 through the composed taps (audio fusion folded in), l >= 2 its own input row
+        const float *xin = l == 1 ? w->OV0.f() : XV(l, r & 1);
+        const size_t arow = (size_t)(r - c.aud_r0) * 4 * D;
+        const long astride = (long)c.aud_rows * 4 * D;
         SkinnyParams g = base_params(B, 4 * D, EPI_GATE);
-        add_dense(g, XV(l, r & 1), 2 * D, 0, 2 * D);
-        g.W = p->wvt[l][1]->f();
+        add_dense(g, xin, 2 * D, 0, 2 * D);
+        g.W = l == 1 ? p->wv1c.f() : p->wvt[l][1]->f();
         if (r > 0) {
             g.add1 = P(l, r & 1);          // Wprev . XV_l[r-1] + bias, computed while row r-1 ran
             g.add1_stride = 4 * D;
         } else {
             g.bias = p->bv[l]->f();        // nothing above the first row
         }
+        if (l == 1) {
+            g.add2 = w->AV1C.f() + arow;   // Wcur_1 . [AEV[r] | AEV[r]]
+            g.add2_stride = astride;
+        }
         gate_common(g, l);
         s.add(g);
-        if (r + 1 < Htot) {
+        if (r + 1 < c.last_row) {
             SkinnyParams q = base_params(B, 4 * D, EPI_LINEAR);
-            add_dense(q, XV(l, r & 1), 2 * D, 0, 2 * D);
-            q.W = p->wvt[l][0]->f();
+            add_dense(q, xin, 2 * D, 0, 2 * D);
+            q.W = l == 1 ? p->wv1p.f() : p->wvt[l][0]->f();
             q.ldw = 2 * D;
             q.bias = p->bv[l]->f();
+            if (l == 1) {
+                q.add1 = w->AV1P.f() + arow;   // Wprev_1 . [AEV[r] | AEV[r]]
+                q.add1_stride = astride;
+            }
             q.out = P(l, (r + 1) & 1);
             q.out_stride = 4 * D;
             s.add(q);
         }
-        if (l >= 2) s.add(make_v2h(l - 1));
+        s.add(make_v2h(l - 1));
         out.push_back(s);
     }
     {
@@ -306,7 +329,7 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
 
 // horizontal chain + head of position (r, j): NL + 2 launch slots (the sampler launch follows separately)
 void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector<Slot> &out) {
-    const int B = c.B, D = p->D, NL = p->NL, Htot = c.Htot;
+    const int B = c.B, D = p->D, NL = p->NL, R = c.R;
     ts_pixelcnn::Work *w = c.w;
     const int *tok = w->tok32.i();
     auto V2H = [&](int l) { return w->V2H.f() + (size_t)l * B * 4 * D + (size_t)j * 2 * D; };
@@ -327,7 +350,7 @@ void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector
     {   // hg_0 — mask 'A': only the column to the left, i.e. the embedding of the code just sampled
         Slot s;
         SkinnyParams q = base_params(B, 2 * D, EPI_GATE);
-        if (j == 1) add_gather(q, p->emb.f(), D, tok + (size_t)r * 2 + 0, (long)Htot * 2, D);
+        if (j == 1) add_gather(q, p->emb.f(), D, tok + (size_t)(r % R) * 2 + 0, (long)R * 2, D);
         q.W = p->wh[0]->f();
         q.ldw = 2 * D;
         q.bias = p->bh[0]->f();
@@ -349,8 +372,8 @@ void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector
         a.ldw = D;
         a.bias = p->rb[l]->f();
         if (l == 1) {
-            a.add1 = w->AEH.f() + (size_t)r * D;
-            a.add1_stride = (long)Htot * D;
+            a.add1 = w->AEH.f() + (size_t)(r - c.aud_r0) * D;
+            a.add1_stride = (long)c.aud_rows * D;
         } else {
             a.add1 = XH(l - 1, j);
             a.add1_stride = D;
@@ -368,8 +391,8 @@ void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector
         g.add1 = V2H(l);
         g.add1_stride = 4 * D;
         if (l == 1) {
-            g.add2 = w->AEH1.f() + (size_t)r * 2 * D;
-            g.add2_stride = (long)Htot * 2 * D;
+            g.add2 = w->AEH1.f() + (size_t)(r - c.aud_r0) * 2 * D;
+            g.add2_stride = (long)c.aud_rows * 2 * D;
         }
         if (j == 1) {
             g.add3 = T0(l);
@@ -417,7 +440,7 @@ int launch_sampler(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s)
     ts_pixelcnn::Work *w = c.w;
     SampleParams sp;
     std::memset(&sp, 0, sizeof(sp));
-    const int ro = r - c.H0;   // row in the caller's (B,H,2) arrays
+    const int ro = r - c.out_r0;   // row in the caller's (B,H,2) arrays
     sp.logits = w->LG.f();
     sp.B = c.B;
     sp.V = p->V;
@@ -427,9 +450,9 @@ int launch_sampler(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s)
     sp.seed = c.seed;
     sp.clip_index0 = c.clip0;
     sp.dyn = c.dyn;
-    sp.position = (uint32_t)(ro * 2 + j);
-    sp.tok32 = w->tok32.i() + (size_t)r * 2 + j;
-    sp.tok_stride = (long)c.Htot * 2;
+    sp.position = (uint32_t)((r - c.pos_r0) * 2 + j + (c.dyn ? 0 : c.pos_base));
+    sp.tok32 = w->tok32.i() + (size_t)(r % c.R) * 2 + j;
+    sp.tok_stride = (long)c.R * 2;
     sp.codes = c.codes + (size_t)ro * 2 + j;
     sp.code_stride = (long)c.H * 2;
     if (c.logits) {
@@ -452,10 +475,9 @@ int run_row(ts_pixelcnn *p, const RunCfg &c, int r, bool need_h, hipStream_t s) 
     build_horizontal(p, c, r, 0, H);
     size_t vi = 0;
     if (p->pair_vh) {
-        // hg_0 needs V2H_0 (V1); S_k needs V2H_k (V_{k+2}): V0, V1 | H0 + V2 | V3 | H1 + V4 | H2 + V5 | ...
+        // hg_0 needs V2H_0 (V1); S_k needs V2H_k (V_{k+1}): V0, V1, H0 + V2, H1 + V3, ...
         for (; vi < 2 && vi < V.size(); ++vi) TS_TRY(launch_slot(ctx, V[vi], nullptr, s));
         for (size_t k = 0; k < H.size(); ++k) {
-            if (k == 1 && vi < V.size()) TS_TRY(launch_slot(ctx, V[vi++], nullptr, s));
             const Slot *ride = nullptr;
             if (vi < V.size() && V[vi].n + H[k].n <= SKINNY_MAX_PROBLEMS) ride = &V[vi++];
             TS_TRY(launch_slot(ctx, H[k], ride, s));
@@ -555,6 +577,35 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
         }
     TS_TRY(p->fva.upload(fa.data(), fa.size() * sizeof(float)));
     TS_TRY(p->fha.upload(fb.data(), fb.size() * sizeof(float)));
+    if (NL > 1) {
+        // layer 1's vertical taps see XV_1 = fusion_v[:, :D] . OV0 + (fusion_v[:, D:] . AE + b) per column.  Compose (fp64,
+        // rounded once): W' = W . blockdiag(F, F) acting on OV0, and Ws = W[:, :D] + W[:, D:] acting on the audio term,
+        // which is the same for both columns (the audio map is repeated over the 2 columns, smplx_body_pixel.py:274).
+        const float *wv1 = sd.get("layers.1.vert_stack.weight", {D2, D, 2, 3});
+        if (!wv1) return 1;
+        for (int t = 0; t < 2; ++t) {   // t = 0: row above (Wprev), t = 1: the row itself (Wcur)
+            std::vector<double> Wt((size_t)2 * D2 * 2 * D);
+            for (int j = 0; j < 2; ++j)
+                for (int co = 0; co < D2; ++co)
+                    for (int cc = 0; cc < 2; ++cc)
+                        for (int ci = 0; ci < D; ++ci)
+                            Wt[((size_t)j * D2 + co) * 2 * D + (size_t)cc * D + ci] =
+                                wv1[(((size_t)co * D + ci) * 2 + t) * 3 + (cc - j + 1)];
+            std::vector<float> Wc((size_t)2 * D2 * 2 * D), Ws((size_t)2 * D2 * D);
+            for (int n = 0; n < 2 * D2; ++n)
+                for (int cc = 0; cc < 2; ++cc)
+                    for (int i = 0; i < D; ++i) {
+                        double a = 0.0;
+                        for (int m = 0; m < D; ++m) a += Wt[(size_t)n * 2 * D + (size_t)cc * D + m] * (double)fa[(size_t)m * D + i];
+                        Wc[(size_t)n * 2 * D + (size_t)cc * D + i] = (float)a;
+                    }
+            for (int n = 0; n < 2 * D2; ++n)
+                for (int i = 0; i < D; ++i)
+                    Ws[(size_t)n * D + i] = (float)(Wt[(size_t)n * 2 * D + i] + Wt[(size_t)n * 2 * D + D + i]);
+            TS_TRY((t == 1 ? p->wv1c : p->wv1p).upload(Wc.data(), Wc.size() * sizeof(float)));
+            TS_TRY(pack_linear_layer(Ws.data(), D, nullptr, 2 * D2, D, t == 1 ? &p->aud_v1c : &p->aud_v1p));
+        }
+    }
     // head
     const float *w1 = sd.get("output_conv.0.weight", {p->HID, D, 1, 1}), *b1 = sd.get("output_conv.0.bias", {p->HID});
     const float *w2 = sd.get("output_conv.2.weight", {V, p->HID, 1, 1}), *b2 = sd.get("output_conv.2.bias", {V});
@@ -664,98 +715,81 @@ void ts_pixelcnn_destroy(ts_pixelcnn *p) { delete p; }
 
 int ts_pixelcnn_graph_stats(ts_pixelcnn *p, void *stream, int B, int H, int mode, int64_t *launches, double *flops) {
     if (!p) return fail("ts_pixelcnn_graph_stats: null argument");
-    auto it = p->works.find((hipStream_t)stream);
-    if (it == p->works.end()) return fail("ts_pixelcnn_graph_stats: nothing was run on this stream");
-    auto jt = it->second->graph_stats.find(std::make_tuple(B, H, 0, mode));
-    if (jt == it->second->graph_stats.end()) return fail("ts_pixelcnn_graph_stats: no captured graph for this shape");
+    ts_pixelcnn::Work *w = p->works.find((hipStream_t)stream);
+    if (!w) return fail("ts_pixelcnn_graph_stats: nothing was run on this stream");
+    auto jt = w->graph_stats.find(std::make_tuple(B, H, 0, mode));
+    if (jt == w->graph_stats.end()) return fail("ts_pixelcnn_graph_stats: no captured graph for this shape");
     if (launches) *launches = jt->second.first;
     if (flops) *flops = jt->second.second;
     return 0;
 }
 
-int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud, int B, int H, int mode,
-                         const float *uniforms, uint64_t seed, int64_t clip0, int64_t *codes, float *logits,
-                         const int64_t *pre_codes, const float *pre_aud, int H0, void *stream) {
-    if (!p || !label || !aud || !codes) return fail("ts_pixelcnn_generate: null argument");
-    if (B < 1 || H < 1 || H0 < 0) return fail("ts_pixelcnn_generate: bad shape");
-    if (mode < 0 || mode > TS_TEACHER_FORCED) return fail("ts_pixelcnn_generate: bad mode");
-    if (mode == TS_SAMPLE_UNIFORMS && !uniforms) return fail("ts_pixelcnn_generate: uniforms required");
-    if (H0 > 0 && (!pre_codes || !pre_aud)) return fail("ts_pixelcnn_generate: prefix pointers required");
-    hipStream_t s = (hipStream_t)stream;
+}  // extern "C"
+
+namespace {
+
+// audio conditioning of `rows` code rows per clip: AE = embedding_aud(aud); AEV / AEH = fusion_{v,h}[:, D:] . AE + bias;
+// AEH1 = layer 1's horiz_stack applied to AEH (gated_pixelcnn_v2.py:137-144) — four conv_gemm launches for all rows at once
+int audio_terms(ts_pixelcnn *p, ts_pixelcnn::Work *w, const float *aud, int B, int rows, hipStream_t s) {
     ts_ctx *ctx = p->ctx;
-    const int Htot = H0 + H, D = p->D, AD = p->AD, NL = p->NL;
-    ts_pixelcnn::Work *w = &p->work(s);
-    TS_TRY(ensure_work(p, w, B, Htot));
-
-    // The row loop is replayed from a hipGraph (host launch cost would otherwise dominate: 70 dependent tiny
-    // launches per row); eager launches remain for the instrumented / logits-returning / teacher-forced paths.
-    const bool graph = p->use_graph && !ctx->prof.on && !logits && mode != TS_TEACHER_FORCED;
-    RunCfg c{B, H, H0, Htot, mode, uniforms, seed, clip0, codes, logits, nullptr, w};
-    if (graph) {
-        c.codes = static_cast<int64_t *>(w->codes_int.p);
-        c.uniforms = mode == TS_SAMPLE_UNIFORMS ? w->unif_int.f() : nullptr;
-        c.dyn = static_cast<const uint64_t *>(w->dyn.p);
-    }
-
-    // ---- audio conditioning for every row: AE = embedding_aud(aud); AEV/AEH = fusion_{v,h}[:, D:] . AE + bias ----
-    const float *aud_all = aud;
-    if (H0 > 0) {
-        const size_t f = sizeof(float);
-        TS_HIP(hipMemcpy2DAsync(w->aud_all.f(), (size_t)Htot * AD * f, pre_aud, (size_t)H0 * AD * f, (size_t)H0 * AD * f,
-                                B, hipMemcpyDeviceToDevice, s));
-        TS_HIP(hipMemcpy2DAsync(w->aud_all.f() + (size_t)H0 * AD, (size_t)Htot * AD * f, aud, (size_t)H * AD * f,
-                                (size_t)H * AD * f, B, hipMemcpyDeviceToDevice, s));
-        aud_all = w->aud_all.f();
-    }
-    {
-        ConvParams q;
-        conv_layer_params(p->aud_embed, aud_all, AD, 1, B * Htot, nullptr, 0, w->AE.f(), D, 0, D, &q);
+    const int D = p->D, AD = p->AD;
+    ConvParams q;
+    conv_layer_params(p->aud_embed, aud, AD, 1, B * rows, nullptr, 0, w->AE.f(), D, 0, D, &q);
+    TS_TRY(run_conv(ctx, q, 0, s));
+    conv_layer_params(p->aud_fv, w->AE.f(), D, 1, B * rows, nullptr, 0, w->AEV.f(), D, 0, D, &q);
+    TS_TRY(run_conv(ctx, q, 0, s));
+    conv_layer_params(p->aud_fh, w->AE.f(), D, 1, B * rows, nullptr, 0, w->AEH.f(), D, 0, D, &q);
+    TS_TRY(run_conv(ctx, q, 0, s));
+    if (p->NL > 1) {
+        conv_layer_params(p->aud_h1, w->AEH.f(), D, 1, B * rows, nullptr, 0, w->AEH1.f(), 2 * D, 0, 2 * D, &q);
         TS_TRY(run_conv(ctx, q, 0, s));
-        conv_layer_params(p->aud_fv, w->AE.f(), D, 1, B * Htot, nullptr, 0, w->AEV.f(), D, 0, D, &q);
+        conv_layer_params(p->aud_v1c, w->AEV.f(), D, 1, B * rows, nullptr, 0, w->AV1C.f(), 4 * D, 0, 4 * D, &q);
         TS_TRY(run_conv(ctx, q, 0, s));
-        conv_layer_params(p->aud_fh, w->AE.f(), D, 1, B * Htot, nullptr, 0, w->AEH.f(), D, 0, D, &q);
+        conv_layer_params(p->aud_v1p, w->AEV.f(), D, 1, B * rows, nullptr, 0, w->AV1P.f(), 4 * D, 0, 4 * D, &q);
         TS_TRY(run_conv(ctx, q, 0, s));
-        if (NL > 1) {   // layer 1's horiz_stack applied to the audio term of XH_1, for every row at once
-            conv_layer_params(p->aud_h1, w->AEH.f(), D, 1, B * Htot, nullptr, 0, w->AEH1.f(), 2 * D, 0, 2 * D, &q);
-            TS_TRY(run_conv(ctx, q, 0, s));
-        }
     }
-    {
-        MiscScope ms(ctx, s);
-        // class conditioning rows: CR[l][b] = class_cond_embedding_l[label[b]]  (h of gated_pixelcnn_v2.py:65)
-        for (int l = 0; l < NL; ++l)
-            TS_HIP(launch_gather_rows(p->cls[l]->f(), 2 * D, p->NC, label, 1, B, 2 * D, w->CR.f() + (size_t)l * B * 2 * D, 2 * D, s));
-        // known codes: the continuity prefix, and every position when teacher forced
-        if (H0 > 0 || mode == TS_TEACHER_FORCED) {
-            int64_t *tf = static_cast<int64_t *>(w->tfcodes.p);
-            const size_t e = sizeof(int64_t);
-            if (H0 > 0)
-                TS_HIP(hipMemcpy2DAsync(tf, (size_t)Htot * 2 * e, pre_codes, (size_t)H0 * 2 * e, (size_t)H0 * 2 * e, B,
-                                        hipMemcpyDeviceToDevice, s));
-            if (mode == TS_TEACHER_FORCED)
-                TS_HIP(hipMemcpy2DAsync(tf + (size_t)H0 * 2, (size_t)Htot * 2 * e, codes, (size_t)H * 2 * e,
-                                        (size_t)H * 2 * e, B, hipMemcpyDeviceToDevice, s));
-            TS_HIP(launch_i64_to_i32(tf, w->tok32.i(), (long)B * Htot * 2, s));
-        }
-    }
+    return 0;
+}
 
+// class conditioning rows: CR[l][b] = class_cond_embedding_l[label[b]]  (h of gated_pixelcnn_v2.py:65)
+int class_rows(ts_pixelcnn *p, ts_pixelcnn::Work *w, const int64_t *label, int B, hipStream_t s) {
+    const int D = p->D;
+    MiscScope ms(p->ctx, s);
+    for (int l = 0; l < p->NL; ++l)
+        TS_HIP(launch_gather_rows(p->cls[l]->f(), 2 * D, p->NC, label, 1, B, 2 * D, w->CR.f() + (size_t)l * B * 2 * D, 2 * D, s));
+    return 0;
+}
+
+// Runs rows [r_begin, r_end) of `c`: eagerly, or as a replay of the hipGraph captured for `key` (host launch cost would
+// otherwise dominate: ~37 dependent tiny launches per row).  On the graph path the kernels write codes into the Work's
+// staging buffer (every pointer inside a captured kernel is a Work buffer, so a graph is valid for any caller pointers).
+int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const std::tuple<int, int, int, int> &key,
+             const float *uniforms, int64_t *codes, hipStream_t s) {
+    ts_ctx *ctx = p->ctx;
+    ts_pixelcnn::Work *w = c.w;
     auto row_loop = [&](hipStream_t st) -> int {
-        for (int r = 0; r < Htot; ++r) {
-            const bool need_h = r >= H0 && !(mode == TS_TEACHER_FORCED && !logits);   // prefix rows only feed the row cache
+        for (int r = r_begin; r < r_end; ++r) {
+            const bool need_h = r >= c.out_r0 && !(c.mode == TS_TEACHER_FORCED && !c.logits);   // prefix rows only feed the row cache
             TS_TRY(run_row(p, c, r, need_h, st));
         }
         return 0;
     };
-    if (!graph) return row_loop(s);
-
-    if (mode == TS_SAMPLE_UNIFORMS)
-        TS_HIP(hipMemcpyAsync(w->unif_int.p, uniforms, (size_t)B * H * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!graph) {
+        c.codes = codes;
+        c.uniforms = uniforms;
+        return row_loop(s);
+    }
+    c.codes = static_cast<int64_t *>(w->codes_int.p);
+    c.uniforms = c.mode == TS_SAMPLE_UNIFORMS ? w->unif_int.f() : nullptr;
+    c.dyn = static_cast<const uint64_t *>(w->dyn.p);
+    if (c.mode == TS_SAMPLE_UNIFORMS)
+        TS_HIP(hipMemcpyAsync(w->unif_int.p, uniforms, (size_t)c.B * c.H * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
     // the host source of the async copy must stay intact until the copy has executed: a ring of 16 slots per Work
     uint64_t *dh = w->dyn_host[w->dyn_slot++ & 15];
-    dh[0] = seed;
-    dh[1] = (uint64_t)clip0;
-    TS_HIP(hipMemcpyAsync(w->dyn.p, dh, 2 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    const auto key = std::make_tuple(B, H, H0, mode);
+    dh[0] = c.seed;
+    dh[1] = (uint64_t)c.clip0;
+    dh[2] = (uint64_t)c.pos_base;
+    TS_HIP(hipMemcpyAsync(w->dyn.p, dh, 3 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     auto it = w->graphs.find(key);
     if (it == w->graphs.end()) {
         if (!w->cap_stream) TS_HIP(hipStreamCreateWithFlags(&w->cap_stream, hipStreamNonBlocking));
@@ -778,7 +812,106 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
         it = w->graphs.emplace(key, ex).first;
     }
     TS_HIP(hipGraphLaunch(it->second, s));
-    TS_HIP(hipMemcpyAsync(codes, w->codes_int.p, (size_t)B * H * 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    TS_HIP(hipMemcpyAsync(codes, w->codes_int.p, (size_t)c.B * c.H * 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud, int B, int H, int mode,
+                         const float *uniforms, uint64_t seed, int64_t clip0, int64_t *codes, float *logits,
+                         const int64_t *pre_codes, const float *pre_aud, int H0, void *stream) {
+    if (!p || !label || !aud || !codes) return fail("ts_pixelcnn_generate: null argument");
+    if (B < 1 || H < 1 || H0 < 0) return fail("ts_pixelcnn_generate: bad shape");
+    if (mode < 0 || mode > TS_TEACHER_FORCED) return fail("ts_pixelcnn_generate: bad mode");
+    if (mode == TS_SAMPLE_UNIFORMS && !uniforms) return fail("ts_pixelcnn_generate: uniforms required");
+    if (H0 > 0 && (!pre_codes || !pre_aud)) return fail("ts_pixelcnn_generate: prefix pointers required");
+    hipStream_t s = (hipStream_t)stream;
+    ts_ctx *ctx = p->ctx;
+    const int Htot = H0 + H, AD = p->AD;
+    ts_pixelcnn::Work *w = &p->work(s);
+    TS_TRY(ensure_work(p, w, B, Htot));
+
+    // eager launches remain for the instrumented / logits-returning / teacher-forced paths
+    const bool graph = p->use_graph && !ctx->prof.on && !logits && mode != TS_TEACHER_FORCED;
+    RunCfg c = one_shot_cfg(B, H, H0, mode, uniforms, seed, clip0, codes, logits, w);
+
+    const float *aud_all = aud;
+    if (H0 > 0) {
+        const size_t f = sizeof(float);
+        TS_HIP(hipMemcpy2DAsync(w->aud_all.f(), (size_t)Htot * AD * f, pre_aud, (size_t)H0 * AD * f, (size_t)H0 * AD * f,
+                                B, hipMemcpyDeviceToDevice, s));
+        TS_HIP(hipMemcpy2DAsync(w->aud_all.f() + (size_t)H0 * AD, (size_t)Htot * AD * f, aud, (size_t)H * AD * f,
+                                (size_t)H * AD * f, B, hipMemcpyDeviceToDevice, s));
+        aud_all = w->aud_all.f();
+    }
+    TS_TRY(audio_terms(p, w, aud_all, B, Htot, s));
+    TS_TRY(class_rows(p, w, label, B, s));
+    // known codes: the continuity prefix, and every position when teacher forced
+    if (H0 > 0 || mode == TS_TEACHER_FORCED) {
+        MiscScope ms(ctx, s);
+        int64_t *tf = static_cast<int64_t *>(w->tfcodes.p);
+        const size_t e = sizeof(int64_t);
+        if (H0 > 0)
+            TS_HIP(hipMemcpy2DAsync(tf, (size_t)Htot * 2 * e, pre_codes, (size_t)H0 * 2 * e, (size_t)H0 * 2 * e, B,
+                                    hipMemcpyDeviceToDevice, s));
+        if (mode == TS_TEACHER_FORCED)
+            TS_HIP(hipMemcpy2DAsync(tf + (size_t)H0 * 2, (size_t)Htot * 2 * e, codes, (size_t)H * 2 * e,
+                                    (size_t)H * 2 * e, B, hipMemcpyDeviceToDevice, s));
+        TS_HIP(launch_i64_to_i32(tf, w->tok32.i(), (long)B * Htot * 2, s));
+    }
+    return run_rows(p, c, 0, Htot, graph, std::make_tuple(B, H, H0, mode), uniforms, codes, s);
+}
+
+// ---- streaming generation (reference: the pre_latents / pre_audio prefix of gated_pixelcnn_v2.py:158-165
+// and its caller smplx_body_pixel.py:260-269,291-304, which recompute the whole prefix for every chunk) --------------------
+int ts_pixelcnn_stream_open(ts_pixelcnn *p, const int64_t *label, int B, int max_chunk_rows, ts_pixelcnn_stream **out) {
+    if (!p || !label || !out) return fail("ts_pixelcnn_stream_open: null argument");
+    if (B < 1 || max_chunk_rows < 1) return fail("ts_pixelcnn_stream_open: bad shape");
+    TS_HIP(hipSetDevice(p->ctx->device));
+    std::unique_ptr<ts_pixelcnn_stream> st(new ts_pixelcnn_stream());
+    st->p = p;
+    st->B = B;
+    st->max_rows = max_chunk_rows;
+    // everything is allocated here, once: growing a buffer later would drop the row cache it holds
+    TS_TRY(ensure_work(p, &st->w, B, std::max(max_chunk_rows, 4)));
+    TS_TRY(st->label.ensure((size_t)B * sizeof(int64_t)));
+    TS_HIP(hipMemcpy(st->label.p, label, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice));
+    *out = st.release();
+    return 0;
+}
+
+void ts_pixelcnn_stream_close(ts_pixelcnn_stream *st) { delete st; }
+
+int64_t ts_pixelcnn_stream_rows(const ts_pixelcnn_stream *st) { return st ? st->rows : -1; }
+
+int ts_pixelcnn_stream_step(ts_pixelcnn_stream *st, const float *aud, int Hc, int mode, const float *uniforms, uint64_t seed,
+                            int64_t clip0, int64_t *codes, void *stream) {
+    if (!st || !aud || !codes) return fail("ts_pixelcnn_stream_step: null argument");
+    if (Hc < 1) return fail("ts_pixelcnn_stream_step: empty chunk");
+    if (Hc > st->max_rows) return fail("ts_pixelcnn_stream_step: chunk longer than max_chunk_rows given to ts_pixelcnn_stream_open");
+    if (mode != TS_SAMPLE_GREEDY && mode != TS_SAMPLE_UNIFORMS && mode != TS_SAMPLE_PHILOX)
+        return fail("ts_pixelcnn_stream_step: bad mode");
+    if (mode == TS_SAMPLE_UNIFORMS && !uniforms) return fail("ts_pixelcnn_stream_step: uniforms required");
+    if (st->rows + Hc > (1l << 30)) return fail("ts_pixelcnn_stream_step: row counter overflow");
+    ts_pixelcnn *p = st->p;
+    ts_ctx *ctx = p->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    ts_pixelcnn::Work *w = &st->w;
+    const int B = st->B, r0 = (int)st->rows;
+    constexpr int RING = 4;   // token rows kept: layer 0 looks three code rows up; 4 also is the period of the Q ring
+    if (r0 == 0) TS_TRY(class_rows(p, w, static_cast<const int64_t *>(st->label.p), B, s));
+    TS_TRY(audio_terms(p, w, aud, B, Hc, s));
+    RunCfg c{B, Hc, 0, r0 + Hc, mode, nullptr, seed, clip0, nullptr, nullptr, nullptr, w,
+             RING, r0, Hc, r0, r0, 2l * r0, 0x7fffffff};
+    // a captured chunk is valid for every start row with the same buffer phases (parity of the per-layer row cache, slot
+    // in the 4-row rings) and the same set of existing rows above (rows 0..2 have fewer): key on that, not on r0
+    const int phase = r0 < 3 ? r0 : 3 + (r0 % 4);
+    const bool graph = p->use_graph && !ctx->prof.on;
+    TS_TRY(run_rows(p, c, r0, r0 + Hc, graph, std::make_tuple(B, Hc, 1000 + phase, mode), uniforms, codes, s));
+    st->rows += Hc;
     return 0;
 }
 

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
             const uint64_t seed = p.dyn ? p.dyn[0] : p.seed;
             const uint64_t clip = (uint64_t)((p.dyn ? (int64_t)p.dyn[1] : p.clip_index0) + b);
             uint32_t r;
-            philox4x32_10(p.position, (uint32_t)clip, (uint32_t)(clip >> 32), 0u, (uint32_t)seed,
+            philox4x32_10(p.position + (p.dyn ? (uint32_t)p.dyn[2] : 0u), (uint32_t)clip, (uint32_t)(clip >> 32), 0u, (uint32_t)seed,
                           (uint32_t)(seed >> 32), r);
             u = (float)(r >> 8) * (1.0f / 16777216.0f);
         }

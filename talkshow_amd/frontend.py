@@ -72,6 +72,64 @@ def resample_sinc_hann(x, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0
     return np.ascontiguousarray(y[:, :target], dtype=F32)
 
 
+_KAISER_BEST = {}
+
+
+def kaiser_best_table():
+    """resampy's published 'kaiser_best' interpolation filter (the resampler behind `librosa.load(sr=...)` in the reference's
+    pinned librosa 0.9.2): right half of a sinc with 64 zero crossings sampled 512 times per crossing, rolloff
+    0.9475937167399596, tapered by a Kaiser window with beta 14.769656459379492.  -> (half_window, deltas, num_table)."""
+    if not _KAISER_BEST:
+        from scipy.signal.windows import kaiser
+        num_zeros, num_table, rolloff, beta = 64, 512, 0.9475937167399596, 14.769656459379492
+        n = num_table * num_zeros
+        sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+        win = (kaiser(2 * n + 1, beta)[n:] * sinc_win).astype(F32)
+        delta = np.zeros_like(win)
+        delta[:-1] = np.diff(win)
+        _KAISER_BEST["t"] = (win, delta, num_table)
+    return _KAISER_BEST["t"]
+
+
+def resample_kaiser_best(x, orig_sr, target_sr):
+    """`librosa.resample(x, orig_sr, target_sr, res_type='kaiser_best', fix=True)` on a mono signal (N,) -> float32
+    (ceil(N * target / orig),): resampy's band-limited interpolation (table lookup + linear interpolation between table
+    entries, left and right wings), then librosa's fix_length.  PARITY UNPINNED (librosa / resampy are not installed)."""
+    x = np.asarray(x, dtype=F32)
+    if orig_sr == target_sr:
+        return x
+    win, delta, num_table = kaiser_best_table()
+    ratio = float(target_sr) / float(orig_sr)
+    n_out = int(x.shape[0] * ratio)
+    scale = min(1.0, ratio)
+    index_step = int(scale * num_table)
+    nwin, n_orig = win.shape[0], x.shape[0]
+    t_reg = np.arange(n_out, dtype=np.float64) / ratio
+    n = t_reg.astype(np.int64)
+    y = np.zeros(n_out, np.float64)
+    xd, wd, dd = x.astype(np.float64), win.astype(np.float64), delta.astype(np.float64)
+    if ratio < 1:                       # resampy: the filter is scaled by the ratio when decimating (unit DC gain)
+        wd, dd = wd * ratio, dd * ratio
+    for wing in (0, 1):
+        frac = scale * (t_reg - n)
+        if wing:
+            frac = scale - frac
+        index_frac = frac * num_table
+        offset = index_frac.astype(np.int64)
+        eta = index_frac - offset
+        taps = (nwin - offset) // index_step
+        limit = np.minimum(n + 1, taps) if wing == 0 else np.minimum(n_orig - n - 1, taps)
+        for i in range(int(limit.max()) if limit.size else 0):
+            live = i < limit
+            k = np.where(live, offset + i * index_step, 0)
+            src = np.where(live, n - i if wing == 0 else n + i + 1, 0)
+            y += np.where(live, (wd[k] + eta * dd[k]) * xd[src], 0.0)
+    target = int(math.ceil(x.shape[0] * ratio))
+    out = np.zeros(target, F32)
+    out[:min(target, n_out)] = y[:target].astype(F32)
+    return out
+
+
 def _hz_to_mel_htk(f):
     return 2595.0 * np.log10(1.0 + f / 700.0)
 
@@ -198,17 +256,29 @@ def get_mfcc_sepa(aud_fn, fps=15, sr=16000, host=None):
     if feat is not None:
         feat = np.asarray(feat, dtype=np.float32)
         return feat, 1 + (2 * sr) // _hop(fps)      # MFCC length of the first 2 s (center=True): the wav path's split
-    wave = _load_mono_resampled(aud_fn, sr)
-    f0 = mfcc(wave[:sr * 2], sr, hop_length=_hop(fps)).T
-    f1 = mfcc(wave[sr * 2:], sr, hop_length=_hop(fps)).T
+    use_host = host if host is not None else not torch.cuda.is_available()
+    hop = _hop(fps)
+    if use_host:
+        wave = _load_mono_resampled(aud_fn, sr)
+        f0 = mfcc(wave[:sr * 2], sr, hop_length=hop).T
+        f1 = mfcc(wave[sr * 2:], sr, hop_length=hop).T
+    else:   # resample the whole clip on the GPU, then the MFCC of the first 2 s and of the rest (two ts_mfcc_forward calls)
+        from .modules import MFCC
+        audio, sr_0 = load_wav(aud_fn)
+        res = MFCC(sr_0, sr, fps)
+        x = torch.stack([res.resample(torch.from_numpy(ch)[None])[0] for ch in audio]).mean(0)     # per channel, then mono
+        plain = MFCC(sr, sr, fps)
+        f0 = plain(x[:sr * 2])[0].cpu().numpy()
+        f1 = plain(x[sr * 2:])[0].cpu().numpy()
     return np.concatenate((f0, f1), axis=0), f0.shape[0]
 
 
-def get_wav16(aud_fn):
+def get_wav16(aud_fn, host=None):
     """Face front-end: `get_mfcc_ta(..., encoder_choice='faceformer')` = `librosa.load(aud_fn, sr=16000)` reshaped to
-    (N, 1), no normalisation (`data_utils/utils.py:194-198`).  Accepted: arrays / tensors of samples, `.npy`, and PCM or
-    float `.wav` files that are ALREADY at 16 kHz (mono = mean of channels, int PCM scaled to [-1, 1) as librosa does);
-    other sample rates need the resampler of the next scope row and raise."""
+    (N, 1), no normalisation (`data_utils/utils.py:194-198`).  Accepted: arrays / tensors of samples (taken to be 16 kHz
+    already), `.npy`, and PCM or float `.wav` files of any sample rate: mono = mean of channels, int PCM scaled to [-1, 1),
+    then librosa's default `kaiser_best` resampling to 16 kHz — on the GPU (`ts_resample_kaiser`) when one is present,
+    else / with `host=True` in numpy (`resample_kaiser_best`, the device kernel's checker)."""
     if isinstance(aud_fn, torch.Tensor):
         x = aud_fn.detach().cpu().numpy()
     elif isinstance(aud_fn, np.ndarray):
@@ -216,14 +286,16 @@ def get_wav16(aud_fn):
     elif str(aud_fn).endswith(".npy"):
         x = np.load(aud_fn)
     elif str(aud_fn).endswith(".wav"):
-        from scipy.io import wavfile
-        sr, x = wavfile.read(aud_fn)
-        if sr != 16000:
-            raise NotImplementedError(f"{aud_fn}: sample rate {sr} != 16000; resampling is the next scope row (SURVEY.md §8f-1)")
-        if np.issubdtype(x.dtype, np.integer):
-            x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
-        if x.ndim == 2:
-            x = x.mean(axis=1)
+        audio, sr = load_wav(aud_fn)                        # (channels, N) float32
+        x = audio.mean(axis=0, dtype=F32) if audio.shape[0] > 1 else audio[0]      # librosa.load: mono first ...
+        if sr != 16000:                                                              # ... then resample (kaiser_best)
+            if host is None:
+                host = not torch.cuda.is_available()
+            if host:
+                x = resample_kaiser_best(x, sr, 16000)
+            else:
+                from .modules import resample_kaiser_device
+                x = resample_kaiser_device(x[None], sr, 16000)[0].cpu().numpy()
     else:
         raise NotImplementedError(f"audio front-end: cannot read {aud_fn!r}")
     return np.asarray(x, dtype=np.float32).reshape(-1, 1)

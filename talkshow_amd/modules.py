@@ -332,6 +332,11 @@ class GatedPixelCNN(NativeModule):
             _lib.stream_ptr()))
         return codes, logits
 
+    def open_stream(self, label, batch_size, max_chunk_rows):
+        """A generation session with a persistent row cache (`ts_pixelcnn_stream_*`): `.step(aud_rows)` continues the
+        clip(s) where the previous step stopped, at a cost independent of the history length."""
+        return PixelCNNStream(self, label, batch_size, max_chunk_rows)
+
     # --- reference call shapes ---
     def generate(self, label, shape=(8, 8), batch_size=64, aud_feat=None, pre_latents=None, pre_audio=None,
                  mode=None, seed=None, uniforms=None):
@@ -356,6 +361,55 @@ class GatedPixelCNN(NativeModule):
         rows = aud[..., 0].transpose(1, 2)
         _, logits = self.run(label, rows, mode=_lib.TS_TEACHER_FORCED, codes=x, want_logits=True)
         return logits.permute(0, 3, 1, 2)
+
+
+class PixelCNNStream:
+    """Host handle of `ts_pixelcnn_stream`: label (B,) or (1,) int64 fixed for the session."""
+
+    def __init__(self, net, label, batch_size, max_chunk_rows):
+        dev = net._dev()
+        label = torch.as_tensor(label, dtype=torch.int64, device=dev).reshape(-1).contiguous()
+        if label.numel() == 1 and batch_size > 1:
+            label = label.repeat(batch_size)
+        if label.numel() != batch_size:
+            raise ValueError(f"label must hold 1 or B={batch_size} class indices, got {label.numel()}")
+        _check_index_range(label, net.n_classes, "class label")
+        self.net, self.B, self.max_rows = net, int(batch_size), int(max_chunk_rows)
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().ts_pixelcnn_stream_open(net.handle(), _lib.dptr(label), self.B, self.max_rows, C.byref(h)))
+        self._h = h
+
+    @property
+    def rows(self):
+        return int(_lib.load().ts_pixelcnn_stream_rows(self._h))
+
+    def step(self, aud_rows, mode=_lib.TS_SAMPLE_PHILOX, uniforms=None, seed=0, clip_index0=0):
+        """aud_rows (B,Hc,aud_dim) device -> codes (B,Hc,2) int64 of the next Hc code rows."""
+        dev = self.net._dev()
+        aud_rows = _dev_f32(aud_rows, dev)
+        B, Hc, _ = aud_rows.shape
+        if B != self.B:
+            raise ValueError(f"session was opened for B={self.B}, got {B}")
+        codes = torch.empty((B, Hc, 2), dtype=torch.int64, device=dev)
+        if uniforms is not None:
+            uniforms = _dev_f32(uniforms, dev)
+        _lib.check(_lib.load().ts_pixelcnn_stream_step(self._h, _lib.dptr(aud_rows), Hc, mode, _lib.dptr(uniforms),
+                                                       int(seed) & (2 ** 64 - 1), int(clip_index0), _lib.dptr(codes),
+                                                       _lib.stream_ptr()))
+        return codes
+
+    def close(self):
+        if self._h is not None:
+            torch.cuda.synchronize()
+            _lib.load().ts_pixelcnn_stream_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class FaceGenerator(NativeModule):
@@ -426,6 +480,16 @@ class MFCC:
         except Exception:
             pass
 
+    def resample(self, wav):
+        """stage 1 alone: wav (B,N) or (N,) at sr_in -> (B,N') at sr_out (torchaudio sinc-Hann polyphase), device tensor."""
+        wav = _dev_f32(wav, self._dev)
+        if wav.ndim == 1:
+            wav = wav[None]
+        B, N = wav.shape
+        out = torch.empty((B, _lib.load().ts_mfcc_resampled_len(self._h, N)), dtype=torch.float32, device=self._dev)
+        _lib.check(_lib.load().ts_mfcc_resample(self._h, _lib.dptr(wav), B, N, _lib.dptr(out), _lib.stream_ptr()))
+        return out
+
     def __call__(self, wav):
         """wav (B,N) or (N,) mono samples at sr_in -> (B,T,64) device tensor."""
         wav = _dev_f32(wav, self._dev)
@@ -436,3 +500,18 @@ class MFCC:
         out = torch.empty((B, T, 64), dtype=torch.float32, device=self._dev)
         _lib.check(_lib.load().ts_mfcc_forward(self._h, _lib.dptr(wav), B, N, _lib.dptr(out), _lib.stream_ptr()))
         return out
+
+
+def resample_kaiser_device(wav, sr_in, sr_out, device=None):
+    """`librosa.resample(..., res_type='kaiser_best')` on the GPU (`ts_resample_kaiser`): wav (B,N) -> (B, ceil(N*sr_out/sr_in))."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    dev = torch.device("cuda", idx if idx is not None else torch.cuda.current_device())
+    wav = _dev_f32(wav, dev)
+    if wav.ndim == 1:
+        wav = wav[None]
+    B, N = wav.shape
+    lib = _lib.load()
+    out = torch.empty((B, lib.ts_resample_kaiser_len(N, int(sr_in), int(sr_out))), dtype=torch.float32, device=dev)
+    _lib.check(lib.ts_resample_kaiser(_lib.context(dev.index), _lib.dptr(wav), B, N, int(sr_in), int(sr_out), _lib.dptr(out),
+                                      _lib.stream_ptr()))
+    return out

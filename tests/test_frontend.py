@@ -126,3 +126,48 @@ def test_whole_mfcc_against_third_party_pipeline():
     got = fe.mfcc(x, 22000)
     assert got.shape == ref.shape
     np.testing.assert_allclose(got, ref, atol=2e-2, rtol=1e-4)               # O(10..1000) coefficients, fp32 pipeline
+
+
+# ---- librosa.load(sr=16000)'s resampler for the face path (resampy 'kaiser_best'; UNPINNED: librosa is not installed) ------
+def test_kaiser_best_table_against_closed_form():
+    """The 32769-entry table == rolloff * sinc(rolloff t) * I0(beta sqrt(1 - (t/64)^2)) / I0(beta) evaluated directly."""
+    from scipy.special import i0
+    win, delta, num_table = fe.kaiser_best_table()
+    assert win.shape == (64 * 512 + 1,) and num_table == 512
+    t = np.arange(win.shape[0]) / 512.0
+    rolloff, beta = 0.9475937167399596, 14.769656459379492
+    ref = rolloff * np.sinc(rolloff * t) * i0(beta * np.sqrt(np.maximum(0.0, 1.0 - (t / 64.0) ** 2))) / i0(beta)
+    np.testing.assert_allclose(win, ref, atol=2e-7)
+    np.testing.assert_allclose(delta[:-1], np.diff(win), atol=0)
+    assert delta[-1] == 0 and abs(win[0] - rolloff) < 1e-7
+
+
+def test_kaiser_best_resampling_properties():
+    x = np.sin(2 * np.pi * 1000 * np.arange(8000) / 8000.0).astype(np.float32)
+    y = fe.resample_kaiser_best(x, 8000, 16000)                       # interpolation: unit-gain filter, exact to ~1e-7
+    assert y.shape == (16000,) and y.dtype == np.float32
+    np.testing.assert_allclose(y[300:-300], np.sin(2 * np.pi * 1000 * np.arange(16000) / 16000.0)[300:-300], atol=1e-6)
+    assert fe.resample_kaiser_best(x, 16000, 16000) is not None and np.array_equal(fe.resample_kaiser_best(x, 16000, 16000), x)
+    # decimation 22.05 kHz -> 16 kHz: length rule ceil(N * ratio) with the last sample zero-filled by fix_length, in-band
+    # tone preserved up to the algorithm's own gain error (index_step = int(scale * 512) truncates: 371 instead of 371.5)
+    n = 22050 + 7
+    z = fe.resample_kaiser_best(np.sin(2 * np.pi * 440 * np.arange(n) / 22050.0).astype(np.float32), 22050, 16000)
+    assert z.shape == (int(np.ceil(n * 16000 / 22050)),)
+    ref = np.sin(2 * np.pi * 440 * np.arange(z.shape[0]) / 16000.0)
+    assert np.abs(z[400:-400] - ref[400:-400]).max() < 3e-3
+    # an out-of-band tone (9 kHz > 8 kHz Nyquist of the target) is removed
+    hi = fe.resample_kaiser_best(np.sin(2 * np.pi * 9000 * np.arange(22050) / 22050.0).astype(np.float32), 22050, 16000)
+    assert np.abs(hi[400:-400]).max() < 2e-2
+
+
+def test_get_wav16_resamples_other_rates(tmp_path):
+    from scipy.io import wavfile
+    sr = 22050
+    t = np.arange(sr) / sr
+    stereo = np.stack([np.sin(2 * np.pi * 300 * t), 0.5 * np.sin(2 * np.pi * 300 * t)], 1)
+    p = str(tmp_path / "a.wav")
+    wavfile.write(p, sr, (stereo * 20000).astype(np.int16))
+    w = fe.get_wav16(p, host=True)
+    assert w.shape == (16000, 1) and w.dtype == np.float32
+    ref = 0.75 * (20000 / 32768.0) * np.sin(2 * np.pi * 300 * np.arange(16000) / 16000.0)
+    assert np.abs(w[400:-400, 0] - ref[400:-400]).max() < 2e-3

@@ -245,6 +245,62 @@ def test_pixelcnn_sampling_and_prefix(hip, golden):
     np.testing.assert_array_equal(tail.cpu().numpy(), g["codes"][:, H0:])
 
 
+def test_pixelcnn_streaming_equals_one_call(hip, golden):
+    """ts_pixelcnn_stream_*: ragged chunks behind a persistent row cache reproduce the one-shot result bit for bit —
+    greedy vs the reference golden, stochastic (Philox position = absolute row) vs the one-shot call."""
+    from talkshow_amd import _lib
+    g = golden("pix_small")
+    m = _pix_module(g["cfg"])
+    B, H = g["codes"].shape[:2]
+    for chunks in ((3, 1, 4, 2), (1,) * H, (H,), (5, 5)):
+        st = m.open_stream(g["label"], B, max(chunks))
+        got, at = [], 0
+        for hc in chunks:
+            got.append(st.step(g["aud"][:, at:at + hc], mode=_lib.TS_SAMPLE_GREEDY))
+            at += hc
+        assert st.rows == H
+        st.close()
+        np.testing.assert_array_equal(torch.cat(got, 1).cpu().numpy(), g["codes"])
+    ref, _ = m.run(g["label"], g["aud"], mode=_lib.TS_SAMPLE_PHILOX, seed=77, clip_index0=5)
+    st = m.open_stream(g["label"], B, 4)
+    got = [st.step(g["aud"][:, a:a + 4], mode=_lib.TS_SAMPLE_PHILOX, seed=77, clip_index0=5) for a in range(0, H, 4)]
+    np.testing.assert_array_equal(torch.cat(got, 1).cpu().numpy(), ref.cpu().numpy())
+    u = O.philox_uniforms(5, 0, B, H)
+    ref_u, _ = m.run(g["label"], g["aud"], mode=_lib.TS_SAMPLE_UNIFORMS, uniforms=u)
+    st2 = m.open_stream(g["label"], B, 3)
+    got = [st2.step(g["aud"][:, a:a + 3], mode=_lib.TS_SAMPLE_UNIFORMS, uniforms=u[:, a:a + 3]) for a in range(0, H, 3)]
+    np.testing.assert_array_equal(torch.cat(got, 1).cpu().numpy(), ref_u.cpu().numpy())
+    with pytest.raises(RuntimeError, match="max_chunk_rows"):
+        st2.step(g["aud"][:, :4], mode=_lib.TS_SAMPLE_GREEDY)
+
+
+def test_streaming_60s_clip_cost_independent_of_history(hip):
+    """A 60 s clip (450 code rows, full-size network) generated in 2 s chunks (15 rows) == the same clip in ONE call, and a
+    late chunk costs what an early one costs (the reference's prefix form re-runs the whole history for every chunk)."""
+    import time
+    from talkshow_amd import _lib
+    from talkshow_amd.modules import GatedPixelCNN
+    m = GatedPixelCNN(2048, 256, 15, 4, True, True).cuda()
+    m.load_state_dict(synth.to_torch(synth.pixelcnn_state_dict(seed=7)))
+    B, H, HC = 2, 450, 15
+    rng = np.random.default_rng(60)
+    aud = torch.from_numpy(rng.standard_normal((B, H, 256)).astype(np.float32)).cuda()
+    label = synth.speaker_ids(B)
+    one, _ = m.run(label, aud, mode=_lib.TS_SAMPLE_GREEDY)
+    st = m.open_stream(label, B, HC)
+    got, cost = [], []
+    for a in range(0, H, HC):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got.append(st.step(aud[:, a:a + HC], mode=_lib.TS_SAMPLE_GREEDY))
+        torch.cuda.synchronize()
+        cost.append(time.perf_counter() - t0)
+    assert torch.equal(torch.cat(got, 1), one)
+    early, late = np.median(cost[6:12]), np.median(cost[-6:])     # past the graph captures of the first phases
+    assert late < 1.25 * early, (early, late)
+    st.close()
+
+
 # ----------------------------------------------------------------------------------------------- wrappers (nets.*)
 def _config(tmp_path, which="body_pixel"):
     vq_path = str(tmp_path / "vq.pth")
@@ -719,3 +775,32 @@ def test_feature_stats_large_and_ragged(hip):
     np.testing.assert_allclose(sig, np.cov(allr, rowvar=False), rtol=1e-8, atol=1e-10)
     with pytest.raises(RuntimeError, match="32, 64 or 128"):
         E.FeatureStats(48).push(np.zeros((4, 48), np.float32))
+
+
+def test_device_kaiser_resampler_and_sepa(hip, tmp_path):
+    """ts_resample_kaiser (face path: librosa.load(sr=16000)'s resampler) and the device get_mfcc_sepa against their numpy
+    twins in talkshow_amd/frontend.py (both restate third-party definitions; the resamplers are unpinned against
+    librosa / torchaudio themselves)."""
+    from scipy.io import wavfile
+    from talkshow_amd import frontend as fe
+    from talkshow_amd.modules import resample_kaiser_device
+    rng = np.random.default_rng(12)
+    for sr_in, n in ((22050, 22050 + 7), (8000, 4000), (44100, 30000), (48000, 48000)):
+        x = (0.3 * rng.standard_normal((2, n))).astype(np.float32)
+        got = resample_kaiser_device(x, sr_in, 16000).cpu().numpy()
+        for b in range(2):
+            ref = fe.resample_kaiser_best(x[b], sr_in, 16000)
+            assert got[b].shape == ref.shape
+            np.testing.assert_allclose(got[b], ref, atol=2e-6, rtol=0)
+    # wav file at 22.05 kHz through the face front-end: device path == host path
+    p = str(tmp_path / "f.wav")
+    wavfile.write(p, 22050, (0.2 * rng.standard_normal((22050, 2))).astype(np.float32))
+    np.testing.assert_allclose(fe.get_wav16(p), fe.get_wav16(p, host=True), atol=2e-6, rtol=0)
+    # get_mfcc_sepa (continuity front-end): device == host restatement, same split frame
+    p2 = str(tmp_path / "b.wav")
+    t = np.arange(16000 * 5) / 16000.0
+    wavfile.write(p2, 16000, (0.2 * np.sin(2 * np.pi * 200 * t) + 0.05 * rng.standard_normal(t.size)).astype(np.float32))
+    fd, gd = fe.get_mfcc_sepa(p2, sr=22000, fps=30)
+    fh, gh = fe.get_mfcc_sepa(p2, sr=22000, fps=30, host=True)
+    assert gd == gh == 1 + 44000 // 734 and fd.shape == fh.shape
+    np.testing.assert_allclose(fd, fh, atol=0.05, rtol=2e-4)
