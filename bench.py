@@ -163,6 +163,29 @@ def face_block(local):
             "other_kernels_ms": msf[2]}
 
 
+def frontend_block(w, _lib, clips):
+    """The audio front-end on the device (a4 / f1), as extra information: `clips` synthetic 10 s 16 kHz waveforms ->
+    sinc-Hann resample to 22 kHz -> MFCC(64) (`ts_mfcc_forward`: 1.26 GMAC of DFT-as-GEMM per clip), alone and in front of
+    one body pass (wav in -> poses out).  The headline's timed region starts from resident MFCC features, as the reference's
+    hot path does after `get_mfcc_ta`; this block shows what wav-in costs on top."""
+    from talkshow_amd import synth
+    from talkshow_amd.modules import MFCC
+    fe = MFCC(16000, 22000, 30)
+    wav = torch.from_numpy(synth.wav16(7000, clips, 160000)).cuda()
+    ids = torch.from_numpy(synth.speaker_ids(clips)).cuda()
+    feat = fe(wav)
+    assert tuple(feat.shape) == (clips, FRAMES_PER_CLIP, 64), feat.shape
+    w.generate_batch(feat, ids, mode=_lib.TS_SAMPLE_GREEDY)
+    t_fe = timed(lambda: fe(wav))
+    t_all = timed(lambda: w.generate_batch(fe(wav), ids, mode=_lib.TS_SAMPLE_GREEDY))
+    t_body = timed(lambda: w.generate_batch(feat, ids, mode=_lib.TS_SAMPLE_GREEDY))
+    return {"workload": f"{clips} x 10 s @16 kHz waveforms resident in HBM -> resample 22 kHz -> MFCC(64, n_fft 2048, hop 734) "
+                        f"[-> audio encoder -> PixelCNN greedy -> VQ decode]",
+            "frontend_ms": t_fe * 1e3, "frontend_ms_per_32_clips": t_fe * 1e3 * 32 / clips,
+            "wav_to_poses_ms": t_all * 1e3, "features_to_poses_ms": t_body * 1e3,
+            "frontend_share_of_wav_to_poses": t_fe / t_all}
+
+
 def diversity_block(w, _lib, mfcc1):
     """BASELINE configs[3] as extra information: num_samples=12 stochastic decodes of ONE 10 s clip (Philox seed 2024)."""
     B = 12
@@ -375,7 +398,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--coalesce", type=int, default=int(os.environ.get("TS_BENCH_COALESCE", "8")),
                     help="submitted batches stacked into one pass (clips per chain stage = batch * coalesce)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("TS_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("TS_BENCH_STREAMS", "3")),
                     help="groups in flight at once, one HIP stream each")
     ap.add_argument("--config", default="body", choices=["body", "whole_body"])
     ap.add_argument("--clips-per-rank", type=int, default=128, help="whole_body: clips per rank per step")
@@ -487,6 +510,10 @@ def main():
             out["diversity"] = diversity_block(w, _lib, mfcc[0])
         except Exception as e:
             out["diversity"] = {"error": repr(e)}
+        try:
+            out["frontend"] = frontend_block(w, _lib, B * G)
+        except Exception as e:
+            out["frontend"] = {"error": repr(e)}
         try:
             out["face"] = face_block(local)
         except Exception as e:                       # the face line is extra information; never lose the main line

@@ -31,7 +31,8 @@ typedef struct ts_convnet ts_convnet;     /* AudioEncoder            nets/spg/vq
 typedef struct ts_vqvae ts_vqvae;         /* VQVAE                   nets/spg/vqvae_1d.py:152-208        */
 typedef struct ts_pixelcnn ts_pixelcnn;   /* GatedPixelCNN           nets/spg/gated_pixelcnn_v2.py:90-177 */
 typedef struct ts_face ts_face;           /* s2g_face.Generator      nets/spg/s2g_face.py:142-224        */
-typedef struct ts_mfcc ts_mfcc;           /* get_mfcc_ta front-end   data_utils/utils.py:148-231         */
+typedef struct ts_mfcc ts_mfcc;
+typedef struct ts_smplx ts_smplx;         /* smplx.SMPLX forward (third-party) scripts/demo.py:122-152, get_j.py */           /* get_mfcc_ta front-end   data_utils/utils.py:148-231         */
 
 /* One entry of a reference state_dict: key name as the reference spells it (an optional "module." prefix is
  * accepted and stripped, nets/smplx_body_pixel.py:119-126), fp32 host data, shape.  int64 buffers
@@ -242,6 +243,28 @@ int ts_pixelcnn_stream_step(ts_pixelcnn_stream *st, const float *aud_dev, int Hc
 /* code rows generated so far */
 int64_t ts_pixelcnn_stream_rows(const ts_pixelcnn_stream *st);
 void ts_pixelcnn_stream_close(ts_pixelcnn_stream *st);
+
+/* ---- batched SMPL-X joints / vertices ----------------------------------------------------------------
+ * Replaces the per-frame float64 CPU calls of smplx.SMPLX.forward in scripts/demo.py:122-152 (get_vertices) and
+ * data_utils/get_j.py:20-50 (get_joints).  Third-party arithmetic (smplx ~= 0.1.28, requirements.txt:5; package and
+ * licensed model file absent): PARITY UNPINNED — the published LBS algorithm restated; fp32 on the device.
+ * Model arrays are HOST float32 / int32 in the package's layouts: v_template (V,3), shapedirs (V,3,n_betas+n_expr) =
+ * cat(shapedirs, expr_dirs), posedirs ((J-1)*9, V*3), J_regressor (J,V), parents (J), lbs_weights (V,J), pose_mean (J*3)
+ * in the package's joint order; pose_src_offset[j] = column of a pose row where joint j's axis-angle starts (TalkSHOW's
+ * 265-d rows: global_orient 9, body 12.., jaw 0, eyes 3 / 6, hands 75.. / 120.., get_j.py:21-30); extra_idx = vertex ids
+ * of vertex_joint_selector, lmk_faces (n_lmk,3) = faces_tensor[lmk_faces_idx], lmk_bary (n_lmk,3).
+ * with_vertices != 0 also uploads the full-mesh blend-shape matrix (V*3 x 896 floats, 112 MB for the real model). */
+int ts_smplx_create(ts_ctx *ctx, int V, int J, int n_betas, int n_expr, const float *v_template, const float *shapedirs,
+                    const float *posedirs, const float *J_regressor, const int32_t *parents, const float *lbs_weights,
+                    const float *pose_mean, const int32_t *pose_src_offset, int n_extra, const int32_t *extra_idx, int n_lmk,
+                    const int32_t *lmk_faces, const float *lmk_bary, int with_vertices, ts_smplx **out);
+void ts_smplx_destroy(ts_smplx *m);
+/* J + n_extra + n_lmk (127 for the reference's model) */
+int ts_smplx_num_joints(const ts_smplx *m);
+/* rows_dev (N,row_ld): pose rows, expression coefficients at columns [expr_off, expr_off + n_expr); betas_dev (n_betas) shared
+ * by all rows, or (N,n_betas) when betas_per_row != 0 -> joints_dev (N, num_joints, 3) and, if not NULL, verts_dev (N,V,3). */
+int ts_smplx_forward(ts_smplx *m, const float *betas_dev, int betas_per_row, const float *rows_dev, int row_ld, int expr_off,
+                     int64_t N, float *joints_dev, float *verts_dev, void *stream);
 
 /* ---- evaluation on the device --------------------------------------------------------------------
  * The reference computes its metrics on the CPU after the hot path (scripts/test_body.py:113-194); these are the

@@ -70,6 +70,11 @@ SIGNATURES = {
     "ts_op_linear": (_i, [_vp, _vp, _i, _i, _fp, _fp, _i, _i, _vp, _vp]),
     "ts_op_sample": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ts_debug_skinny_chain": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
+    "ts_smplx_create": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, C.POINTER(C.c_int32), _fp, _fp, C.POINTER(C.c_int32), _i,
+                             C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32), _fp, _i, C.POINTER(_vp)]),
+    "ts_smplx_destroy": (None, [_vp]),
+    "ts_smplx_num_joints": (_i, [_vp]),
+    "ts_smplx_forward": (_i, [_vp, _vp, _i, _vp, _i, _i, _i64, _vp, _vp, _vp]),
     "ts_eval_feat_stats": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "ts_eval_l1_total": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "ts_eval_body_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

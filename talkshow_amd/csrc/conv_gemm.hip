@@ -231,6 +231,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
 
     // ---- epilogue: bias (+ residual) + activation, masked store ----
+    // the 16 residual values of an accumulator block are fetched together, ahead of their use (one load-to-use round trip per
+    // block instead of one per element: the stack-tail layers ran 4-33 % slower than their residual-free neighbours)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + li;
@@ -238,16 +240,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         const bool nok = n < p.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float rv[16];
+            if (gres) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    rv[r] = (nok && m < p.M) ? gres[(long)m * p.ldr + n] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (nok && m < p.M) {
                     float v = acc[i][j][r] + bv;
-                    if (gres && !p.res_after_act) v += gres[(long)m * p.ldr + n];
+                    if (gres && !p.res_after_act) v += rv[r];
                     if (p.act == 1) v = v >= 0.f ? v : v * 0.2f;
                     else if (p.act == 2) v = v > 0.f ? v : 0.f;
                     else if (p.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (gres && p.res_after_act) v += gres[(long)m * p.ldr + n];
+                    if (gres && p.res_after_act) v += rv[r];
                     gout[(long)m * p.ldo + g.out_col0 + n] = v;
                 }
             }
@@ -268,12 +278,18 @@ static int pick_tile(const ConvParams &p) {
     // inside the real layer sequence (304-335 us vs 298-310 us for 64x64), so the model does not pick it.
     struct Cand { int id, bm, bn; double eff; };
     static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.92}, {3, 128, 64, 0.95}, {4, 64, 128, 0.95}};
+    static const int big = [] { const char *e = getenv("TS_CONV_BIG"); return e ? atoi(e) : 0; }();   // 8 / 9: try the 256-wide tiles
     int best = 2;
     double best_cost = 1e300;
     for (const Cand &c : cands) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * p.ngroups;
         const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
         if (cost < best_cost) { best_cost = cost; best = c.id; }
+    }
+    if (big == 8 || big == 9) {   // experimental: only where at least ~4 waves of the big tile exist
+        const int bm = big == 8 ? 256 : 128, bn = big == 8 ? 128 : 256;
+        const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ngroups;
+        if (tiles >= 1000 && p.N % bn == 0) return big;
     }
     return best;
 }
@@ -302,6 +318,10 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
         // tiles, one per CU in a single wave, with the L2->LDS traffic per MAC of the 128x128 tile
         case 6: hipLaunchKernelGGL((conv_gemm_kernel<160, 128, 160, 32>), grid(160, 128), block, 0, stream, p); break;
         case 7: hipLaunchKernelGGL((conv_gemm_kernel<96, 128, 96, 32>), grid(96, 128), block, 0, stream, p); break;
+        // 256-wide tiles, one workgroup (one wave per SIMD, up to 512 registers) per CU: 0.047 operand bytes per MAC instead
+        // of 0.0625 — the kernel is bound by what a CU can pull through its L1 (~10-11 B/clk), not by the matrix pipe
+        case 8: hipLaunchKernelGGL((conv_gemm_kernel<256, 128, 128, 64>), grid(256, 128), block, 0, stream, p); break;
+        case 9: hipLaunchKernelGGL((conv_gemm_kernel<128, 256, 64, 128>), grid(128, 256), block, 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

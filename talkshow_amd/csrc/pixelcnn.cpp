@@ -351,6 +351,8 @@ void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector
         Slot s;
         SkinnyParams q = base_params(B, 2 * D, EPI_GATE);
         if (j == 1) add_gather(q, p->emb.f(), D, tok + (size_t)(r % R) * 2 + 0, (long)R * 2, D);
+        else add_dense(q, nullptr, 0, 0, 128);   // column 0 has nothing to its left: a block of zero rows keeps the launch on
+                                                 // the descriptor kernel (K = 0 would drop the whole launch to the generic one)
         q.W = p->wh[0]->f();
         q.ldw = 2 * D;
         q.bias = p->bh[0]->f();

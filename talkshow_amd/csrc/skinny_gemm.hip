@@ -394,7 +394,15 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 4 ? W / 2 : 1)) void skinny16_fa
     int dws[SKINNY_MAX_PROBLEMS];
 #pragma unroll
     for (int i = 0; i < SKINNY_MAX_PROBLEMS; ++i) dws[i] = (int)batch.d[i].w[lane];
-    const int bx = blockIdx.x;
+    // XCD-aware order (coalesced batches): the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each
+    // with a private L2.  Workgroup id b is given logical tile (b % 8) * (n / 8) + b / 8, so that one XCD owns a
+    // CONTIGUOUS eighth of the (problem, column tile) space: it pulls only its eighth of the stage's weights through the
+    // fabric and its row tiles re-read them from its own L2 (tiles are enumerated column-major inside a problem).
+    int bx = blockIdx.x;
+    if (batch.start[6] & 1) {
+        const int per = (int)gridDim.x >> 3;
+        if (bx < per * 8) bx = (bx & 7) * per + (bx >> 3);
+    }
     int z = 0, first = 0;
 #pragma unroll
     for (int i = 1; i < SKINNY_MAX_PROBLEMS; ++i) {
@@ -409,11 +417,11 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 4 ? W / 2 : 1)) void skinny16_fa
         return (gcf *)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(dw, k + 1) << 32) |
                        (uint64_t)(uint32_t)__builtin_amdgcn_readlane(dw, k));
     };
-    const int gx = I(SD_GX) / CB;               // column tiles of this shape (SD_GX counts 16-column tiles)
-    const int mt = (bx - first) / gx, tile = (bx - first) - mt * gx;
+    const int M = I(SD_M), N = I(SD_N), flags = I(SD_FLAGS), gateD = I(SD_GATED);
+    const int nmt = (M + ROWS - 1) / ROWS;      // row tiles; tiles of a problem are enumerated column-major
+    const int tile = (bx - first) / nmt, mt = (bx - first) - tile * nmt;
     if (TRACE) tr[1] = wall_clock64();
 
-    const int M = I(SD_M), N = I(SD_N), flags = I(SD_FLAGS), gateD = I(SD_GATED);
     const bool gate = flags & SDF_GATE;
     int n[CB], nc[CB];
     bool n_ok[CB];
@@ -773,6 +781,8 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
             const int rows = RB * 16;
             int total = 0;
             for (int i = 0; i < 8; ++i) db.start[i] = 0x7fffffff;
+            static const int xcd_min = [] { const char *e = getenv("TS_SKINNY_XCD_MIN_M"); return e ? atoi(e) : (1 << 30); }();
+            db.start[6] = maxM >= xcd_min ? 1 : 0;     // XCD-aware tile order: measured SLOWER (M = 256: 52.8 vs 45.2 ms per pass), off
             for (int i = 0; i < n && fast; ++i) {
                 fast = skinny_pack_desc(b.p[i], W16, g_zero[dev], db.d[i]);
                 db.start[i] = total;

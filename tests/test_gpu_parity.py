@@ -83,7 +83,7 @@ def test_conv_tile_shapes_agree(hip):
     ref = np.where(ref >= 0, ref, 0.2 * ref).astype(np.float32)
     xd, wd, bd = dev(x), dev(w), dev(b)
     outs = {}
-    for tile in (1, 2, 3, 4, 5, 6, 7, 0):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 0):
         out = torch.full((B, L, Cout), float("nan"), dtype=torch.float32, device="cuda")
         _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, tile, 1,
                                           _lib.dptr(out), None, None))
@@ -804,3 +804,36 @@ def test_device_kaiser_resampler_and_sepa(hip, tmp_path):
     fh, gh = fe.get_mfcc_sepa(p2, sr=22000, fps=30, host=True)
     assert gd == gh == 1 + 44000 // 734 and fd.shape == fh.shape
     np.testing.assert_allclose(fd, fh, atol=0.05, rtol=2e-4)
+
+
+# ----------------------------------------------------------------------------------------------- SMPL-X joints / vertices
+@pytest.mark.parametrize("V,with_vertices", [(700, True), (10475, False)])
+def test_smplx_layer_vs_oracle(hip, V, with_vertices):
+    """Batched SMPL-X forward on the device (csrc/smplx.*) vs the float64 numpy restatement of smplx's published LBS
+    (oracle/smplx_oracle.py) on synthetic model parameters of the real model's structure; V = 10475 is the real mesh size."""
+    from oracle import smplx_oracle as SO
+    from talkshow_amd.smplx_lbs import SMPLXLayer
+    model = SO.synthetic_model(seed=3, V=V)
+    layer = SMPLXLayer(model, with_vertices=with_vertices)
+    assert layer.num_joints == 55 + 21 + 51
+    rng = np.random.default_rng(V)
+    B, T = 2, 9
+    rows = (rng.standard_normal((B, T, 265)) * 0.35).astype(np.float32)
+    rows[0, 0, 3:9] = 0.0                                      # zero eye poses: Rodrigues of the zero vector
+    rows[..., 165:] *= 3.0                                     # expression coefficients are O(1)
+    betas = (rng.standard_normal(300) * 0.8).astype(np.float32)
+    ref_j, ref_v = SO.smplx_forward(model, betas, rows.reshape(-1, 265))
+    if with_vertices:
+        joints, verts = layer.vertices(betas, rows)
+        assert verts.shape == (B, T, V, 3)
+        np.testing.assert_allclose(verts.cpu().numpy().reshape(-1, V, 3), ref_v, atol=1e-4, rtol=0)
+    else:
+        joints = layer.joints(betas, rows)
+        with pytest.raises(RuntimeError, match="with_vertices"):
+            layer.vertices(betas, rows)
+    assert joints.shape == (B, T, 127, 3)
+    np.testing.assert_allclose(joints.cpu().numpy().reshape(-1, 127, 3), ref_j, atol=1e-4, rtol=0)     # metres
+    # one betas row per pose row + run-to-run determinism
+    bb = np.repeat(betas[None], B * T, 0)
+    j2 = layer.joints(bb, rows)
+    assert torch.equal(j2, joints)

@@ -19,7 +19,8 @@ shapes = [(75, 1024, 1024, 3), (150, 512, 512, 3), (300, 256, 256, 3), (300, 64,
           (15999, 512, 512, 3)]
 if os.environ.get("TS_TUNE_FEW"):
     shapes = [(75, 1024, 1024, 3), (150, 512, 512, 3), (300, 256, 256, 3), (128, 4096, 4096, 1), (600, 768, 3072, 1)]
-names = {0: "auto", 1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 5: "64x64k64", 6: "160x128", 7: "96x128"}
+names = {0: "auto", 1: "128x128", 2: "64x64", 3: "128x64", 4: "64x128", 5: "64x64k64", 6: "160x128", 7: "96x128", 8: "256x128",
+         9: "128x256"}
 for (L, Cin, Cout, K) in shapes:
     x = torch.randn(B, L, Cin, device="cuda")
     npad = (Cout + 127) // 128 * 128
@@ -28,7 +29,7 @@ for (L, Cin, Cout, K) in shapes:
     out = torch.empty(B, L, Cout, device="cuda")
     flops = 2.0 * B * L * Cout * K * Cin
     row = []
-    for tile in (0, 1, 2, 3, 4, 6, 7):
+    for tile in [int(t) for t in os.environ.get("TS_TILES", "0,1,2,3,4,6,7,8,9").split(",")]:
         ms = C.c_float()
         _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(x), B, L, Cin, _lib.dptr(w), _lib.dptr(b), Cout, K, tile, 20,
                                           _lib.dptr(out), C.byref(ms), None))
