@@ -7,10 +7,11 @@ One step = BASELINE.json configs[1]: one batch of 32 synthetic 10 s clips throug
 inputs resident in HBM before the timed region, fp32, seeded random-init weights of the reference architecture.
 value = generated frames / s over all ranks (32 * 300 frames per step per rank).
 
-How the steps are executed (serving-style, `--coalesce G --streams S`): a step SUBMITS its batch; every G submitted
-batches are stacked and go through the path as one pass of 32*G clips (the autoregressive chain is latency-bound below
-~64 clips per stage: one pass over 256 clips streams each stage's weights once instead of 8 times), alternating over S
-HIP streams so that the conv stacks of one group overlap the chain of another.  A clip's result does not depend on how
+How the steps are executed (serving-style, `--coalesce G --streams S`): the K steps of a run are K queued batches; the
+engine stacks up to G of them per pass (spread evenly over a multiple of S passes) and each pass goes through the path as
+one pass of up to 32*G clips (the autoregressive chain is latency-bound below ~64 clips per stage: one pass over 256 clips
+streams each stage's weights once instead of 8 times), on S HIP streams so that the conv stacks of one pass overlap the
+chain of another.  A clip's result does not depend on how
 its batch was grouped (bit-identical; tests/test_gpu_parity.py::test_golden_clips_inside_baseline_batches).  Every
 step's batch is completely processed inside the timed region.  The strict one-batch-at-a-time figure and the round-1
 mode (4 independent batches on 4 streams, no coalescing) are measured beside it (`modes`).
@@ -261,58 +262,56 @@ def conv_roofline(lib, _lib, local, run_pass):
 class Engine:
     """configs[1] executor: submit() a 32-clip batch per step; groups of G batches run as one pass on alternating streams."""
 
-    def __init__(self, w, lib, _lib, streams, B, T, G, mfcc, gt, ids, rank):
+    def __init__(self, w, lib, _lib, streams, B, T, G, mfcc, gt, ids, rank, enc_streams=None):
         self.w, self.lib, self._lib = w, lib, _lib
         S = len(streams)
         self.B, self.T, self.H, self.G, self.S = B, T, T // 4, G, S
         self.mfcc, self.gt, self.rank = mfcc, gt, rank
         self.dev = mfcc[0].device
         self.streams = streams
+        self.enc_streams = enc_streams     # optional: the VQ-encode half of a pass on its own stream(s) (it feeds nothing downstream)
         self.ids_rep = ids.repeat(G).contiguous()
         self.gt_codes = [torch.empty((B * G, self.H, 2), dtype=torch.int64, device=self.dev) for _ in range(S)]
-        self.pending, self.groups, self.last = [], 0, None
+        self.last = None
 
     def run_group(self, ks, stream_index):
         NB, B, T, lib, _lib, w = len(self.mfcc), self.B, self.T, self.lib, self._lib, self.w
-        with torch.cuda.stream(self.streams[stream_index]):
-            s = _lib.stream_ptr()
-            n = B * len(ks)
-            if len(ks) == 1:
-                gtc, mfc = self.gt[ks[0] % NB], self.mfcc[ks[0] % NB]
-            else:   # stacking the resident batches is part of the pass (device copies on the pass's stream)
-                gtc = torch.cat([self.gt[k % NB] for k in ks], 0)
-                mfc = torch.cat([self.mfcc[k % NB] for k in ks], 0)
+        n = B * len(ks)
+
+        def encode():
             # VQ-VAE encode half of configs[1] (VQVAE.encode of the 300 GT frames, body and hand)
+            gtc = self.gt[ks[0] % NB] if len(ks) == 1 else torch.cat([self.gt[k % NB] for k in ks], 0)
             _lib.check(lib.ts_body_vq_infer(w.g_body.handle(), w.g_hand.handle(), _lib.dptr(gtc), n, T,
-                                            _lib.dptr(self.gt_codes[stream_index][:n]), None, s))
+                                            _lib.dptr(self.gt_codes[stream_index][:n]), None, _lib.stream_ptr()))
+        if self.enc_streams:
+            with torch.cuda.stream(self.enc_streams[stream_index % len(self.enc_streams)]):
+                encode()
+        with torch.cuda.stream(self.streams[stream_index]):
+            if not self.enc_streams:
+                encode()
+            # stacking the resident batches is part of the pass (device copies on the pass's stream)
+            mfc = self.mfcc[ks[0] % NB] if len(ks) == 1 else torch.cat([self.mfcc[k % NB] for k in ks], 0)
             # audio encoder -> PixelCNN greedy -> VQ decode
             self.last = w.generate_batch(mfc, self.ids_rep[:n], mode=_lib.TS_SAMPLE_GREEDY, clip_index0=self.rank * B)
         return self.last
 
-    def submit(self, k):
-        self.pending.append(k)
-        if len(self.pending) == self.G:
-            self.flush()
-
-    def flush(self):
-        if self.pending:
-            ks, self.pending = self.pending, []
-            self.run_group(ks, self.groups % self.S)
-            self.groups += 1
+    def plan(self, steps):
+        """How `steps` queued batches are grouped into passes: full passes of G batches, then the remainder.  (Spreading
+        them evenly instead — 20 steps as 7, 7, 6 rather than 8, 8, 4 — measured 5 % SLOWER: a chain pass costs almost the
+        same for 192, 224 or 256 clips, so partly filled passes waste it.)"""
+        full, rest = divmod(steps, self.G)
+        return [self.G] * full + ([rest] if rest else [])
 
     def run_steps(self, steps):
-        self.groups = 0
-        for k in range(steps):
-            self.submit(k)
-        self.flush()
+        k = 0
+        for gi, size in enumerate(self.plan(steps)):
+            self.run_group(list(range(k, k + size)), gi % self.S)
+            k += size
         return self.last
 
     def warm(self, steps):
-        """graph capture + scratch allocation for every (group size, stream) the timed steps will use"""
-        sizes = {self.G} if steps >= self.G else set()
-        if steps % self.G:
-            sizes.add(steps % self.G)
-        for g in sorted(sizes):
+        """graph capture + scratch allocation for every (pass size, stream) the timed steps will use"""
+        for g in sorted(set(self.plan(steps))):
             for si in range(self.S):
                 self.run_group(list(range(g)), si)
         torch.cuda.synchronize()
@@ -400,6 +399,8 @@ def main():
                     help="submitted batches stacked into one pass (clips per chain stage = batch * coalesce)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("TS_BENCH_STREAMS", "3")),
                     help="groups in flight at once, one HIP stream each")
+    ap.add_argument("--enc-streams", type=int, default=int(os.environ.get("TS_BENCH_ENC_STREAMS", "0")),
+                    help="run the VQ-encode half of each pass on this many extra streams (0 = on the pass's own stream)")
     ap.add_argument("--config", default="body", choices=["body", "whole_body"])
     ap.add_argument("--clips-per-rank", type=int, default=128, help="whole_body: clips per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -439,7 +440,8 @@ def main():
     G, S = max(1, a.coalesce), max(1, a.streams)
     # one pool of library streams, created back to back (distinct hardware queues); every execution mode draws from it
     pool = _lib.create_streams(max(S, 1 if a.no_modes else 4), local)
-    eng = Engine(w, lib, _lib, pool[:S], B, T, G, mfcc, gt, ids, rank)
+    enc_pool = _lib.create_streams(a.enc_streams, local) if a.enc_streams > 0 else None
+    eng = Engine(w, lib, _lib, pool[:S], B, T, G, mfcc, gt, ids, rank, enc_streams=enc_pool)
 
     def barrier():
         if world > 1:
@@ -447,7 +449,7 @@ def main():
 
     torch.cuda.synchronize()
     eng.warm(a.steps)
-    eng.run_steps(-(-max(a.warmup, 1) // G) * G)       # >= W untimed steps through the same submit/flush path (whole groups)
+    eng.run_steps(max(a.warmup, 1))                    # W untimed steps (passes of sizes the warm-up above has seen or captures now)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
@@ -471,8 +473,9 @@ def main():
         "dtype": "f32", "data": "synthetic (seeded MFCC-scale features / poses, random-init weights of the reference architecture)",
         "config": {"workload": "BASELINE configs[1]: batch=32 x 10 s clips, body+hand VQ-VAE encode -> PixelCNN greedy decode -> VQ decode, 30 fps",
                    "batch_per_gpu": B, "frames_per_clip": FRAMES_PER_CLIP, "coalesce": G, "streams": S,
-                   "parallelism": f"clip-sharded x{world}; per GPU every {G} submitted batches run as one pass of {B * G} clips, "
-                                  f"{S} passes in flight (one HIP stream each)"},
+                   "batches_per_pass": eng.plan(a.steps),
+                   "parallelism": f"clip-sharded x{world}; per GPU the queued batches run as passes of up to {G} batches "
+                                  f"({B * G} clips), {S} passes in flight (one HIP stream each)"},
         "per_gpu_frames_per_s": frames / dt / world,
     }
     # whole path against the fp32 MFMA roof: algorithmic work of configs[1] (64.25 MFLOP per generated frame)

@@ -201,11 +201,13 @@ struct Slot {   // one launch: up to SKINNY_MAX_PROBLEMS independent problems
 };
 
 int launch_slot(ts_ctx *ctx, const Slot &a, const Slot *b, hipStream_t s) {
+    // workgroups are dispatched in problem order: the rider (vertical stack: the big K = 512 problems) goes first, so that
+    // whatever does not fit the first round of workgroups is the cheap end of the launch
     const SkinnyParams *ps[SKINNY_MAX_PROBLEMS];
     int n = 0;
-    for (int i = 0; i < a.n; ++i) ps[n++] = &a.p[i];
     if (b)
         for (int i = 0; i < b->n; ++i) ps[n++] = &b->p[i];
+    for (int i = a.n - 1; i >= 0; --i) ps[n++] = &a.p[i];
     return run_skinny_batch(ctx, ps, n, s);
 }
 

@@ -344,14 +344,14 @@ template <int V> struct IC { static constexpr int value = V; };
 
 // One q-step (16 k) of a wave: RB row blocks x CB column blocks of 16x16 outputs share RB + CB 16-byte operand loads.
 template <int RB, int CB>
-__device__ __forceinline__ void skinny16_load_step(gcf *const (&ap)[4], gcf *const (&bp)[2], int u, f32x4 (&a)[4], f32x4 (&b)[2]) {
+__device__ __forceinline__ void skinny16_load_step(gcf *const (&ap)[4], gcf *const (&bp)[4], int u, f32x4 (&a)[4], f32x4 (&b)[4]) {
 #pragma unroll
     for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<gcf4 *>(bp[c] + u * 16);
 #pragma unroll
     for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<gcf4 *>(ap[r] + u * 16);
 }
 template <int RB, int CB>
-__device__ __forceinline__ void skinny16_mfma_step(const f32x4 (&a)[4], const f32x4 (&b)[2], f32x4 (&acc)[8]) {
+__device__ __forceinline__ void skinny16_mfma_step(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x4 (&acc)[16]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -372,12 +372,13 @@ static unsigned g_trace_seq = 0;          // host: sequence number handed to the
 // Tile = RB x CB blocks of 16 x 16 outputs (one v_mfma_f32_16x16x4_f32 accumulator each):
 //   (1,1) 16 rows x 16 columns   a single chain whose launch still fits one workgroup per CU: least bytes per CU
 //   (2,1) 32 x 16                one batch of <= 32 clips
-//   (2,2) 32 x 32, (4,2) 64 x 32 coalesced batches (M >= 64 clips per stage): the stage turns from latency- into
-//                                L2-bandwidth-bound, and a tile's operand bytes per output go 256 / 192 -> 128 / 96 B
+//   (2,2) 32 x 32, (4,2) 64 x 32, (4,4) 64 x 64   coalesced batches (M >= 64 clips per stage): a launch is then bound by the
+//                                operand bytes a CU pulls through its L1; bytes per output 256 / 192 ->
+//                                128 / 96 / 64 B.  (4,4) runs one workgroup per CU (128 KB of LDS for the reduction)
 // Every block of every tile shape is accumulated in the same order (same K split over the waves, same MFMA, same LDS
 // summation order), so a clip's result does not depend on the tile shape its batch happened to get: bit-identical.
 template <int W, int RB, int CB, bool TRACE = false>
-__global__ __launch_bounds__(W * 64, (RB * CB > 4 ? W / 2 : 1)) void skinny16_fast_kernel(const SkinnyDescBatch batch) {
+__global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2 : 1))) void skinny16_fast_kernel(const SkinnyDescBatch batch) {
     constexpr int ROWS = RB * 16;
     constexpr int NBLK = RB * CB;
     constexpr int NREG = NBLK * 4;              // accumulator registers per lane to reduce across the waves
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 4 ? W / 2 : 1)) void skinny16_fa
     gci *gidx = (gci *)P(sbase + 2);
     const int row_stride = I(sbase + 4), row_shift = I(sbase + 6);
     const int koff = (q0 - qs) * 16 + lg * 4;
-    gcf *ap[4], *bp[2];
+    gcf *ap[4], *bp[4];
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const int m = mt * ROWS + r * 16 + li;
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 4 ? W / 2 : 1)) void skinny16_fa
 #pragma unroll
     for (int c = 0; c < CB; ++c) bp[c] = P(SD_W) + (long)nc[c] * I(SD_LDW) + q0 * 16 + lg * 4;
 
-    f32x4 acc[8];
+    f32x4 acc[16];
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int RPW = NREG >= W ? NREG / W : 1;   // registers finished by each (active) wave
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 4 ? W / 2 : 1)) void skinny16_fa
     if (NBLK <= 2) {
         // phase 1: every load of this wave — K operands first (they are waited for first), then the epilogue operands;
         // phase 2: the MFMAs.  Straight-line code per q-step count.
-        f32x4 a[8][4], b[8][2];
+        f32x4 a[8][4], b[8][4];
         auto phase1 = [&](auto cnt_c) {
             constexpr int CNT = decltype(cnt_c)::value;
 #pragma unroll
@@ -533,19 +534,19 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 4 ? W / 2 : 1)) void skinny16_fa
         else phase2(IC<3>{});
     } else {
         // fat tiles (cnt <= 4, host-checked): (RB + CB) x cnt 16-byte loads would not leave room for a second workgroup on
-        // the CU, so the A operand is fetched two q-steps ahead while the (shared, colder) weight rows all go out at once
-        f32x4 a[2][4], b[4][2];
+        // the CU, so the A operand is fetched two q-steps ahead of its use while the weight rows of all steps go out early.
+        // Loads are issued STEP-MAJOR (B0 A0 B1 A1 B2 B3): vmcnt retires in order, so the MFMAs of step 0 only wait for the
+        // first RB + CB loads and run under the rest of the stream (issued weight-rows-first they waited for 3/4 of it)
+        f32x4 a[2][4], b[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (u < cnt) {
 #pragma unroll
                 for (int c = 0; c < CB; ++c) b[u][c] = *reinterpret_cast<gcf4 *>(bp[c] + u * 16);
-            }
+                if (u < 2) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (u < cnt) {
-#pragma unroll
-                for (int r = 0; r < RB; ++r) a[u][r] = *reinterpret_cast<gcf4 *>(ap[r] + u * 16);
+                    for (int r = 0; r < RB; ++r) a[u][r] = *reinterpret_cast<gcf4 *>(ap[r] + u * 16);
+                }
             }
         __builtin_amdgcn_sched_barrier(0);
         if (TRACE) t_loads = wall_clock64();
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 4 ? W / 2 : 1)) void skinny16_fa
 #pragma unroll
                     for (int r = 0; r < RB; ++r) a[u & 1][r] = *reinterpret_cast<gcf4 *>(ap[r] + (u + 2) * 16);
                 }
+                __builtin_amdgcn_sched_barrier(0);   // keep step u's MFMAs ahead of the waits of step u+1
             }
         epilogue_operands();   // issued behind the last MFMAs (not live during the main loop: registers)
     }
@@ -767,15 +769,21 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
                 return t;
             };
             int RB = 2, CB = 1;
+            bool quad = even;
+            for (int i = 0; i < n; ++i)
+                if (b.p[i].grid_x % 4) quad = false;
             if (force_shape) {
                 RB = force_shape / 10;
                 CB = force_shape % 10;
-                if (!even || maxcnt > 4) CB = 1;
+                if (CB == 4 && (!quad || maxcnt > 4)) CB = 2;
+                if (CB == 2 && (!even || maxcnt > 4)) CB = 1;
                 if (CB == 1 && RB > 2) RB = 2;
             } else if (maxM <= 32) {
                 if (count(16, 1) <= half_max) RB = 1;
             } else if (even && maxcnt <= 4) {
-                if (count(64, 2) >= fat_min) { RB = 4; CB = 2; }
+                static const int quad_max = [] { const char *e = getenv("TS_SKINNY_QUAD_MAX"); return e ? atoi(e) : 0; }();
+                if (quad && quad_max > 0 && count(64, 4) >= fat_min && count(64, 4) <= quad_max) { RB = 4; CB = 4; }
+                else if (count(64, 2) >= fat_min) { RB = 4; CB = 2; }
                 else if (count(32, 2) >= fat_min) { RB = 2; CB = 2; }
             }
             const int rows = RB * 16;
@@ -794,20 +802,26 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
                 static const int trace = [] { const char *e = getenv("TS_SKINNY_TRACE"); return e ? atoi(e) : 0; }();
                 if (trace) db.start[7] = (int)(g_trace_seq++);
                 const int shape = RB * 10 + CB;
+                // TS_SKINNY_PAD_LDS: extra dynamic LDS per workgroup (occupancy experiments: e.g. 24576 caps the 64 x 32 tile
+                // at one workgroup per CU so that a conv_gemm workgroup of another stream can sit beside it)
+                static const int pad_lds = [] { const char *e = getenv("TS_SKINNY_PAD_LDS"); return e ? atoi(e) : 0; }();
+                const int dyn_lds = (RB * CB == 8) ? pad_lds : 0;
 #define TS_SK_LAUNCH(Wv, R, C)                                                                                         \
     do {                                                                                                               \
-        if (trace) hipLaunchKernelGGL((skinny16_fast_kernel<Wv, R, C, true>), grid, dim3(Wv * 64), 0, stream, db);     \
-        else hipLaunchKernelGGL((skinny16_fast_kernel<Wv, R, C, false>), grid, dim3(Wv * 64), 0, stream, db);          \
+        if (trace) hipLaunchKernelGGL((skinny16_fast_kernel<Wv, R, C, true>), grid, dim3(Wv * 64), dyn_lds, stream, db); \
+        else hipLaunchKernelGGL((skinny16_fast_kernel<Wv, R, C, false>), grid, dim3(Wv * 64), dyn_lds, stream, db);     \
     } while (0)
                 if (W16 == 8) {
                     if (shape == 11) TS_SK_LAUNCH(8, 1, 1);
                     else if (shape == 21) TS_SK_LAUNCH(8, 2, 1);
                     else if (shape == 22) TS_SK_LAUNCH(8, 2, 2);
+                    else if (shape == 44) TS_SK_LAUNCH(8, 4, 4);
                     else TS_SK_LAUNCH(8, 4, 2);
                 } else {
                     if (shape == 11) TS_SK_LAUNCH(4, 1, 1);
                     else if (shape == 21) TS_SK_LAUNCH(4, 2, 1);
                     else if (shape == 22) TS_SK_LAUNCH(4, 2, 2);
+                    else if (shape == 44) TS_SK_LAUNCH(4, 4, 4);
                     else TS_SK_LAUNCH(4, 4, 2);
                 }
 #undef TS_SK_LAUNCH

@@ -669,8 +669,9 @@ def test_device_mfcc_vs_host_restatement(hip, tmp_path):
 
 
 @pytest.mark.parametrize("env", [{"TS_SKINNY_V": "0"}, {"TS_NO_GRAPH": "1"}, {"TS_SKINNY_NT": "32"},
-                                 {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"}],
-                         ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32"])
+                                 {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"}, {"TS_SKINNY_SHAPE": "44"}],
+                         ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
+                              "tile_64x64"])
 def test_alternate_kernel_paths(hip, env):
     """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
     launches, the 32-column kernel).  The knobs are read once per process, so the golden-vector tests are re-run in a child

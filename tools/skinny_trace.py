@@ -15,7 +15,7 @@ from talkshow_amd import _lib, synth
 
 lib = _lib.load()
 w, _ = bench.build_models(0)
-B, T, H = 32, 300, 75
+B, T, H = int(os.environ.get("TS_B", "32")), 300, 75
 dev = torch.device("cuda", 0)
 mfcc = torch.from_numpy(synth.mfcc_features(1000, B, T)).to(dev)
 ids = torch.from_numpy(synth.speaker_ids(B)).to(dev)
