@@ -12,8 +12,8 @@
 //   h_vert_l(r) = Wcur_l . XV_l[r] + ( Wprev_l . XV_l[r-1] + b )         the bracket is computed one row EARLIER, in the
 //   h_vert_0(r) = W2 . E[r-1] + ( W1 . E[r-2] ) + ( W0 . E[r-3] ) + b     same launch that first sees XV_l[r-1] / E[..]
 //
-// Launch plan of row r (every entry is ONE skinny_gemm launch over all B clips; "|" separates independent problems that
-// share a launch, blockIdx.z):
+// Launch plan of row r (every entry is ONE skinny_gemm launch over all clips of the pass; "|" separates independent
+// problems that share a launch):
 //   V0        v0.gate | v0.Q1 | v0.Q0                     gate: OV0 = gate(W2.E[r-1] + Q1[r] + Q0[r] + b + c0)
 //   V1        v1.gate | v1.P | v2h_0                      layer 1 reads OV0 directly: fusion_v[:, :D] (gated_pixelcnn_v2.py:137-144)
 //                                                         is composed into its two tap matrices on the host, the audio half
@@ -32,8 +32,12 @@
 //   head1'   relu( (W1.Wr_{NL-1}) . G_{NL-1} + W1 . XH_{NL-1}[j] + b )
 // A and B only need (G_{l-1}, XH_{l-1}) so they share a launch: NL + 2 dependent launches per column instead of 2*NL + 3.
 // The vertical stack of a row and the column-0 chain of the same row are independent except for V2H_l (ready after
-// V_{l+2}); V_k rides in the launch of the column-0 stage that runs one step behind it: 2 + (NL + 4) + (NL + 2) + 2
-// = 40 dependent launches per row for NL = 15 instead of 2 + 17 + 66.
+// V_{l+1}); V_k rides in the launch of the column-0 stage that runs one step behind it: V0, V1, then (hg_0 | V2),
+// (S_1 | V3), ... = 2 + (NL + 2) + (NL + 2) = 36 skinny launches per row for NL = 15, plus the 2 sampler launches
+// (a per-op port would need 2 + 17 + 66).
+//
+// Rows are absolute indices: a one-shot call runs rows 0..H-1 (after an optional known prefix), a streaming session
+// (ts_pixelcnn_stream_*) continues at the row where its previous step stopped, on a row cache that persists in its Work.
 #include <algorithm>
 #include <cstdlib>
 #include <tuple>
@@ -49,7 +53,7 @@ struct ts_pixelcnn {
     std::vector<std::vector<std::unique_ptr<DevBuf>>> wvt;   // vertical taps: layer 0 {W0,W1,W2}, l>=1 {Wprev,Wcur}; each [4D][2D]
     std::vector<std::unique_ptr<DevBuf>> bv;                 // [2*2D] (duplicated per column)
     std::vector<std::unique_ptr<DevBuf>> wv2h, bv2h, wh, bh, cls, wr, br;
-    DevBuf fva, fha;                                         // fusion_{v,h}[:, :D]  [D][D]
+    DevBuf fha;                                              // fusion_h[:, :D]  [D][D] (fusion_v's half lives composed in wv1c / wv1p)
     DevBuf wv1c, wv1p;                                       // layer 1 vertical taps with fusion_v[:, :D] composed in  [4D][2D]
     ConvLayer aud_v1c, aud_v1p;                              // the same taps applied to the audio half of the fusion   [4D][D]
     ConvLayer aud_embed, aud_fv, aud_fh;                     // embedding_aud ; fusion_{v,h}[:, D:] (+ fusion bias)
@@ -579,7 +583,6 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
             fa[(size_t)o * D + i] = wfv[(size_t)o * D2 + i];
             fb[(size_t)o * D + i] = wfh[(size_t)o * D2 + i];
         }
-    TS_TRY(p->fva.upload(fa.data(), fa.size() * sizeof(float)));
     TS_TRY(p->fha.upload(fb.data(), fb.size() * sizeof(float)));
     if (NL > 1) {
         // layer 1's vertical taps see XV_1 = fusion_v[:, :D] . OV0 + (fusion_v[:, D:] . AE + b) per column.  Compose (fp64,
