@@ -68,6 +68,7 @@ struct SkinnySeg {
     long gidx_stride;
     int row_shift;
     int len;             // multiple of 8
+    int tiled_w;         // 0 = row-major; else the buffer is TILED with this row width (see SkinnyParams::w_tiled)
 };
 
 enum { EPI_LINEAR = 0, EPI_GATE = 1 };
@@ -99,6 +100,17 @@ struct SkinnyParams {
     float *pre;          // EPI_GATE optional: pre-activation (acc + bias + add1 + add2, without clsrow) [M][pre_stride]
     long pre_stride;
     int grid_x, grid_y;  // filled by the launcher
+    // ---- tiled operand layouts (descriptor kernel only) ----
+    // A wave's MFMA operand fragment is 16 rows x 16 k: lane (i = lane & 15, g = lane >> 4) holds k = 16 q + 4 g .. + 3 of row i.
+    // Row-major, one wave load touches 16 rows x 64 B — measured at 14 B/clk/CU from a warm L2 against 34-42 B/clk for a
+    // contiguous 1 KB (tools/fetch_rate.cpp).  A TILED buffer stores each such fragment contiguously, in lane order:
+    //   float index of element (m, k) of a [rows][W] array = (((m >> 4) * (W >> 4) + (k >> 4)) << 8) + (((m & 15) + 16 * ((k & 15) >> 2)) << 2) + (k & 3)
+    // rows padded to a multiple of 16, W a power of two >= 16.  Weights: tile t (16 output columns, in the epilogue's
+    // column order), q-step q at ((t * (K / 16) + q) << 8), same lane order.
+    int w_tiled;         // 0: W is row-major [N][ldw]; else W is the tiled copy and this is K / 16
+    int out_tiled_w;     // 0 or the row width of the tiled view `out` is written in (element (row, col) = linear row * out_stride + col)
+    int pre_tiled_w;     // same for `pre`
+    int add1_tiled_w;    // same for reading `add1`
 };
 
 // up to SKINNY_MAX_PROBLEMS INDEPENDENT problems share one launch (blockIdx.z): one kernel boundary on the dependent chain
@@ -106,6 +118,11 @@ struct SkinnyBatch {
     SkinnyParams p[SKINNY_MAX_PROBLEMS];
 };
 
+// host-side: the tiled copy of a weight matrix W [N][ldw] (K columns used) for epilogue `epi` (column order of EPI_GATE tiles:
+// 8 "tanh" channels followed by their 8 "sigmoid" partners); out has ceil(N/16) * (K/16) * 256 floats
+void skinny_tile_weights(const float *W, int N, int K, long ldw, int epi, int gateD, float *out);
+// false if an environment knob forces the generic kernels (which do not read tiled operands)
+bool skinny_descriptor_kernel_enabled();
 hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream);
 hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t stream);
 // allocates the per-device zero buffer the fast skinny kernel substitutes for absent operands (call once per device,

@@ -65,6 +65,14 @@ struct ts_pixelcnn {
     ConvLayer aud_h1;                                        // Wh1_1 applied to AEH for every row (l = 1 has AEH in place of XH_0)
     bool use_graph = true;
     bool pair_vh = true;
+    // tiled operand layouts (kernels.h, SkinnyParams::w_tiled): every weight matrix of the chain gets a tiled twin, and
+    // the activation buffers that feed the next stage's GEMM (OV0, XV, HV, G, XH, Y) are written / read tiled
+    bool tiled = false;
+    struct TiledW {
+        DevBuf buf;
+        int K = 0, epi = 0;
+    };
+    std::map<const float *, std::unique_ptr<TiledW>> wtiled;
     // Work set: every buffer the row loop touches + the hipGraph replays of it.  One per stream, so that independent
     // batches can be in flight on different streams against the single weight copy above.
     struct Work {
@@ -113,27 +121,28 @@ int ensure_work(ts_pixelcnn *p, ts_pixelcnn::Work *w, int B, int Htot) {
     if (B <= w->capB && Htot <= w->capH) return 0;
     const int cb = std::max(B, w->capB), ch = std::max(Htot, w->capH);
     const size_t D = p->D, NL = p->NL, f = sizeof(float);
+    const size_t cb16 = round_up(cb, 16);   // tiled buffers hold whole 16-row blocks
     TS_TRY(w->aud_all.ensure((size_t)cb * ch * p->AD * f));
     TS_TRY(w->AE.ensure((size_t)cb * ch * D * f));
     TS_TRY(w->AEV.ensure((size_t)cb * ch * D * f));
     TS_TRY(w->AEH.ensure((size_t)cb * ch * D * f));
     TS_TRY(w->tok32.ensure((size_t)cb * ch * 2 * sizeof(int)));
     TS_TRY(w->CR.ensure(NL * cb * 2 * D * f));
-    TS_TRY(w->XV.ensure(NL * 2 * cb * 2 * D * f));
-    TS_TRY(w->OV0.ensure((size_t)cb * 2 * D * f));
+    TS_TRY(w->XV.ensure(NL * 2 * cb16 * 2 * D * f));
+    TS_TRY(w->OV0.ensure(cb16 * 2 * D * f));
     TS_TRY(w->OVlast.ensure((size_t)cb * 2 * D * f));
-    TS_TRY(w->HV.ensure(NL * cb * 4 * D * f));
+    TS_TRY(w->HV.ensure(NL * cb16 * 4 * D * f));
     TS_TRY(w->V2H.ensure(NL * cb * 4 * D * f));
     TS_TRY(w->P.ensure(NL * 2 * cb * 4 * D * f));
     TS_TRY(w->Q1.ensure((size_t)4 * cb * 4 * D * f));
     TS_TRY(w->Q0.ensure((size_t)4 * cb * 4 * D * f));
-    TS_TRY(w->XH.ensure((NL + 1) * 2 * cb * D * f));
-    TS_TRY(w->G.ensure((size_t)2 * cb * D * f));
+    TS_TRY(w->XH.ensure((NL + 1) * 2 * cb16 * D * f));
+    TS_TRY(w->G.ensure((size_t)2 * cb16 * D * f));
     TS_TRY(w->T0.ensure(NL * cb * 2 * D * f));
     TS_TRY(w->AEH1.ensure((size_t)cb * ch * 2 * D * f));
     TS_TRY(w->AV1C.ensure((size_t)cb * ch * 4 * D * f));
     TS_TRY(w->AV1P.ensure((size_t)cb * ch * 4 * D * f));
-    TS_TRY(w->Y.ensure((size_t)cb * p->HID * f));
+    TS_TRY(w->Y.ensure(cb16 * p->HID * f));
     TS_TRY(w->LG.ensure((size_t)cb * p->V * f));
     TS_TRY(w->tfcodes.ensure((size_t)cb * ch * 2 * sizeof(int64_t)));
     TS_TRY(w->codes_int.ensure((size_t)cb * ch * 2 * sizeof(int64_t)));
@@ -204,15 +213,41 @@ struct Slot {   // one launch: up to SKINNY_MAX_PROBLEMS independent problems
     void add(const SkinnyParams &q) { p[n++] = q; }
 };
 
-int launch_slot(ts_ctx *ctx, const Slot &a, const Slot *b, hipStream_t s) {
+// the tiled view width of the work buffer that holds `ptr`, or 0 (row-major buffers / foreign pointers)
+int tiled_width_of(const ts_pixelcnn *p, const ts_pixelcnn::Work *w, const void *ptr) {
+    if (!p->tiled || !ptr) return 0;
+    auto in = [&](const DevBuf &b) { return ptr >= b.p && ptr < static_cast<const char *>(b.p) + b.bytes; };
+    if (in(w->OV0) || in(w->XV) || in(w->HV)) return 2 * p->D;     // HV is [B][4D], read by v2h as [2B][2D]
+    if (in(w->G) || in(w->XH)) return p->D;
+    if (in(w->Y)) return p->HID;
+    return 0;
+}
+
+int launch_slot(ts_pixelcnn *p, ts_pixelcnn::Work *w, const Slot &a, const Slot *b, hipStream_t s) {
     // workgroups are dispatched in problem order: the rider (vertical stack: the big K = 512 problems) goes first, so that
     // whatever does not fit the first round of workgroups is the cheap end of the launch
+    SkinnyParams q[SKINNY_MAX_PROBLEMS];
     const SkinnyParams *ps[SKINNY_MAX_PROBLEMS];
     int n = 0;
     if (b)
-        for (int i = 0; i < b->n; ++i) ps[n++] = &b->p[i];
-    for (int i = a.n - 1; i >= 0; --i) ps[n++] = &a.p[i];
-    return run_skinny_batch(ctx, ps, n, s);
+        for (int i = 0; i < b->n; ++i) q[n++] = b->p[i];
+    for (int i = a.n - 1; i >= 0; --i) q[n++] = a.p[i];
+    for (int i = 0; i < n; ++i) {
+        if (p->tiled) {   // operands by identity: tiled weight twin, tiled activation buffers (see ts_pixelcnn::tiled)
+            auto it = p->wtiled.find(q[i].W);
+            if (it != p->wtiled.end() && it->second->K == q[i].Ktot && it->second->epi == q[i].epi) {
+                q[i].W = it->second->buf.f();
+                q[i].w_tiled = q[i].Ktot / 16;
+            }
+            for (int k = 0; k < q[i].nseg; ++k)
+                if (!q[i].seg[k].gidx) q[i].seg[k].tiled_w = tiled_width_of(p, w, q[i].seg[k].base);
+            q[i].out_tiled_w = tiled_width_of(p, w, q[i].out);
+            q[i].pre_tiled_w = tiled_width_of(p, w, q[i].pre);
+            q[i].add1_tiled_w = tiled_width_of(p, w, q[i].add1);
+        }
+        ps[i] = &q[i];
+    }
+    return run_skinny_batch(p->ctx, ps, n, s);
 }
 
 // vertical stack + v->h projections of row r as NL+2 launch slots
@@ -220,8 +255,9 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
     const int B = c.B, D = p->D, NL = p->NL, R = c.R;
     ts_pixelcnn::Work *w = c.w;
     const int *tok = w->tok32.i();
-    auto XV = [&](int l, int par) { return w->XV.f() + ((size_t)(l * 2 + par) * B) * 2 * D; };
-    auto HV = [&](int l) { return w->HV.f() + (size_t)l * B * 4 * D; };
+    const size_t Bp = round_up(B, 16);   // slices of the tiled buffers are whole 16-row blocks apart
+    auto XV = [&](int l, int par) { return w->XV.f() + ((size_t)(l * 2 + par) * Bp) * 2 * D; };
+    auto HV = [&](int l) { return w->HV.f() + (size_t)l * Bp * 4 * D; };
     auto V2H = [&](int l) { return w->V2H.f() + (size_t)l * B * 4 * D; };
     auto P = [&](int l, int par) { return w->P.f() + ((size_t)(l * 2 + par) * B) * 4 * D; };
     auto Q = [&](DevBuf &q, int row) { return q.f() + (size_t)(row & 3) * B * 4 * D; };
@@ -257,6 +293,7 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
         Slot s;
         SkinnyParams g = base_params(B, 4 * D, EPI_GATE);
         if (r >= 1) emb_row(g, r - 1);
+        else add_dense(g, nullptr, 0, 0, 128);   // top row: bias + conditioning only (a zero segment keeps it on the descriptor kernel)
         g.W = p->wvt[0][2]->f();
         g.bias = p->bv[0]->f();
         if (r >= 2) {
@@ -339,9 +376,10 @@ void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector
     ts_pixelcnn::Work *w = c.w;
     const int *tok = w->tok32.i();
     auto V2H = [&](int l) { return w->V2H.f() + (size_t)l * B * 4 * D + (size_t)j * 2 * D; };
-    auto XH = [&](int l, int col) { return w->XH.f() + ((size_t)(l * 2 + col) * B) * D; };
+    const size_t Bp = round_up(B, 16);
+    auto XH = [&](int l, int col) { return w->XH.f() + ((size_t)(l * 2 + col) * Bp) * D; };
     auto CR = [&](int l) { return w->CR.f() + (size_t)l * B * 2 * D; };
-    auto G = [&](int l) { return w->G.f() + (size_t)(l & 1) * B * D; };
+    auto G = [&](int l) { return w->G.f() + (size_t)(l & 1) * Bp * D; };
     auto T0 = [&](int l) { return w->T0.f() + (size_t)l * B * 2 * D; };
     auto make_t0 = [&](int l) {   // column 0 only: Wh0_l . XH_l[0], consumed by column 1's S_l
         SkinnyParams t = base_params(B, 2 * D, EPI_LINEAR);
@@ -473,31 +511,30 @@ int launch_sampler(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s)
 }
 
 int run_row(ts_pixelcnn *p, const RunCfg &c, int r, bool need_h, hipStream_t s) {
-    ts_ctx *ctx = p->ctx;
     std::vector<Slot> V, H;
     build_vertical(p, c, r, V);
     if (!need_h) {
-        for (auto &sl : V) TS_TRY(launch_slot(ctx, sl, nullptr, s));
+        for (auto &sl : V) TS_TRY(launch_slot(p, c.w, sl, nullptr, s));
         return 0;
     }
     build_horizontal(p, c, r, 0, H);
     size_t vi = 0;
     if (p->pair_vh) {
         // hg_0 needs V2H_0 (V1); S_k needs V2H_k (V_{k+1}): V0, V1, H0 + V2, H1 + V3, ...
-        for (; vi < 2 && vi < V.size(); ++vi) TS_TRY(launch_slot(ctx, V[vi], nullptr, s));
+        for (; vi < 2 && vi < V.size(); ++vi) TS_TRY(launch_slot(p, c.w, V[vi], nullptr, s));
         for (size_t k = 0; k < H.size(); ++k) {
             const Slot *ride = nullptr;
             if (vi < V.size() && V[vi].n + H[k].n <= SKINNY_MAX_PROBLEMS) ride = &V[vi++];
-            TS_TRY(launch_slot(ctx, H[k], ride, s));
+            TS_TRY(launch_slot(p, c.w, H[k], ride, s));
         }
-        for (; vi < V.size(); ++vi) TS_TRY(launch_slot(ctx, V[vi], nullptr, s));   // only if the stack outlasts the chain
+        for (; vi < V.size(); ++vi) TS_TRY(launch_slot(p, c.w, V[vi], nullptr, s));   // only if the stack outlasts the chain
     } else {
-        for (auto &sl : V) TS_TRY(launch_slot(ctx, sl, nullptr, s));
-        for (auto &sl : H) TS_TRY(launch_slot(ctx, sl, nullptr, s));
+        for (auto &sl : V) TS_TRY(launch_slot(p, c.w, sl, nullptr, s));
+        for (auto &sl : H) TS_TRY(launch_slot(p, c.w, sl, nullptr, s));
     }
     TS_TRY(launch_sampler(p, c, r, 0, s));
     build_horizontal(p, c, r, 1, H);
-    for (auto &sl : H) TS_TRY(launch_slot(ctx, sl, nullptr, s));
+    for (auto &sl : H) TS_TRY(launch_slot(p, c.w, sl, nullptr, s));
     return launch_sampler(p, c, r, 1, s);
 }
 
@@ -712,6 +749,43 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
             TS_TRY(p->w1m.upload(wm.data(), wm.size() * sizeof(float)));
             TS_TRY(p->b1m.upload(bf.data(), bf.size() * sizeof(float)));
         }
+    }
+    // ---- tiled twins of every weight matrix the chain multiplies with (see ts_pixelcnn::tiled) ----
+    p->tiled = skinny_descriptor_kernel_enabled() && D % 128 == 0 && p->HID % 128 == 0 && V % 16 == 0;
+    if (p->tiled) {
+        auto tile = [&](const DevBuf &rm, int N, int K, long ldw, int epi, int gateD) -> int {
+            std::vector<float> host((size_t)N * ldw);
+            TS_HIP(hipMemcpy(host.data(), rm.p, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+            std::vector<float> t((size_t)((N + 15) / 16) * (K / 16) * 256);
+            skinny_tile_weights(host.data(), N, K, ldw, epi, gateD, t.data());
+            std::unique_ptr<ts_pixelcnn::TiledW> tw(new ts_pixelcnn::TiledW());
+            tw->K = K;
+            tw->epi = epi;
+            TS_TRY(tw->buf.upload(t.data(), t.size() * sizeof(float)));
+            p->wtiled[rm.f()] = std::move(tw);
+            return 0;
+        };
+        const int D4 = 4 * D;
+        TS_TRY(tile(*p->wvt[0][2], D4, D2, D2, EPI_GATE, D));                              // V0 gate (the two code rows gathered: K = 2D)
+        TS_TRY(tile(*p->wvt[0][0], D4, D2, D2, EPI_LINEAR, 0));                            // Q0 / Q1
+        TS_TRY(tile(*p->wvt[0][1], D4, D2, D2, EPI_LINEAR, 0));
+        for (int l = 1; l < NL; ++l) {
+            if (l >= 2) {
+                TS_TRY(tile(*p->wvt[l][1], D4, D2, D2, EPI_GATE, D));
+                TS_TRY(tile(*p->wvt[l][0], D4, D2, D2, EPI_LINEAR, 0));
+            }
+            TS_TRY(tile(*p->wh[l], D2, D, D2, EPI_LINEAR, 0));                             // t0: tap-0 block of horiz_stack
+            TS_TRY(tile(*p->rw[l], D, D, D, EPI_LINEAR, 0));
+            TS_TRY(tile(*p->wB[l], D2, l == 1 ? D : D2, l == 1 ? D : D2, EPI_GATE, D));
+        }
+        for (int l = 0; l < NL; ++l) TS_TRY(tile(*p->wv2h[l], D2, D2, D2, EPI_LINEAR, 0));
+        TS_TRY(tile(*p->wh[0], D2, D, D2, EPI_GATE, D));                                   // hg_0 of column 1 (K = D gather)
+        if (NL > 1) {
+            TS_TRY(tile(p->wv1c, D4, D2, D2, EPI_GATE, D));
+            TS_TRY(tile(p->wv1p, D4, D2, D2, EPI_LINEAR, 0));
+        }
+        TS_TRY(tile(p->w1m, p->HID, NL >= 2 ? D2 : D, NL >= 2 ? D2 : D, EPI_LINEAR, 0));
+        TS_TRY(tile(p->w2, V, p->HID, p->HID, EPI_LINEAR, 0));
     }
     if (const char *e = std::getenv("TS_NO_GRAPH")) p->use_graph = !(e[0] && e[0] != '0');
     if (const char *e = std::getenv("TS_NO_PAIR")) p->pair_vh = !(e[0] && e[0] != '0');

@@ -326,8 +326,20 @@ enum {   // descriptor word indices
     SD_SEG = 33,   // per segment: base(2) gidx(2) row_stride gidx_stride row_shift len16
     SD_SEG_WORDS = 8,
     SD_ZERO = 57,
+    SD_WTQ = 59,       // K / 16 when the weights are tiled, else 0
+    SD_OUT_TW = 60,    // log2 of the tiled view width of out / pre / add1, or 0 (row-major)
+    SD_PRE_TW = 61,
+    SD_ADD1_TW = 62,
 };
 enum { SDF_GATE = 1, SDF_RELU = 2, SDF_PRE = 4 };
+constexpr int SEG_TILED = 0x10000;   // segment word 6: SEG_TILED | (W / 16) for a tiled dense segment
+
+// float index of element `lin` (= row * row_width + col) of a buffer tiled with view width 2^lw
+__device__ __forceinline__ long tiled_index(long lin, int lw) {
+    const long m = lin >> lw;
+    const int k = (int)(lin - (m << lw));
+    return ((((m >> 4) << (lw - 4)) + (k >> 4)) << 8) + ((int)((m & 15) + (((k & 15) >> 2) << 4)) << 2) + (k & 3);
+}
 struct SkinnyDesc { uint32_t w[64]; };
 struct SkinnyDescBatch {
     int start[8];   // first workgroup of problem i (1-D grid over live tiles only); INT_MAX for unused problems
@@ -344,11 +356,12 @@ template <int V> struct IC { static constexpr int value = V; };
 
 // One q-step (16 k) of a wave: RB row blocks x CB column blocks of 16x16 outputs share RB + CB 16-byte operand loads.
 template <int RB, int CB>
-__device__ __forceinline__ void skinny16_load_step(gcf *const (&ap)[4], gcf *const (&bp)[4], int u, f32x4 (&a)[4], f32x4 (&b)[4]) {
+__device__ __forceinline__ void skinny16_load_step(gcf *const (&ap)[4], gcf *const (&bp)[4], int u, int astep, int bstep,
+                                                   f32x4 (&a)[4], f32x4 (&b)[4]) {
 #pragma unroll
-    for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<gcf4 *>(bp[c] + u * 16);
+    for (int c = 0; c < CB; ++c) b[c] = *reinterpret_cast<gcf4 *>(bp[c] + u * bstep);
 #pragma unroll
-    for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<gcf4 *>(ap[r] + u * 16);
+    for (int r = 0; r < RB; ++r) a[r] = *reinterpret_cast<gcf4 *>(ap[r] + u * astep);
 }
 template <int RB, int CB>
 __device__ __forceinline__ void skinny16_mfma_step(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x4 (&acc)[16]) {
@@ -459,7 +472,9 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
     }
     gcf *base = P(sbase);
     gci *gidx = (gci *)P(sbase + 2);
-    const int row_stride = I(sbase + 4), row_shift = I(sbase + 6);
+    const int row_stride = I(sbase + 4), segw = I(sbase + 6);
+    const bool a_tiled = segw & SEG_TILED;          // wave-uniform
+    const int astep = a_tiled ? 256 : 16;           // floats between consecutive q-steps of this wave's A stream
     const int koff = (q0 - qs) * 16 + lg * 4;
     gcf *ap[4], *bp[4];
 #pragma unroll
@@ -469,12 +484,21 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
         if (gidx) {   // wave-uniform: token-embedding gather (one extra round trip, first stage of column 1 only)
             const int g = gidx[(long)mc * I(sbase + 5)];
             ap[r] = (g >= 0 ? base + (long)g * row_stride : P(SD_ZERO)) + koff;
+        } else if (a_tiled) {   // fragment (row block, q) is one contiguous KB in lane order
+            const int nblk = (M + 15) >> 4;
+            int blk = mt * RB + r;
+            blk = blk < nblk ? blk : nblk - 1;
+            ap[r] = base + ((((long)blk * (segw & 0xffff) + (q0 - qs)) << 6) + lane) * 4;
         } else {
-            ap[r] = base + (long)(mc >> row_shift) * row_stride + koff;
+            ap[r] = base + (long)mc * row_stride + koff;
         }
     }
+    const int wtq = I(SD_WTQ);
+    const int bstep = wtq ? 256 : 16;
 #pragma unroll
-    for (int c = 0; c < CB; ++c) bp[c] = P(SD_W) + (long)nc[c] * I(SD_LDW) + q0 * 16 + lg * 4;
+    for (int c = 0; c < CB; ++c)
+        bp[c] = wtq ? P(SD_W) + ((((long)(tile * CB + c) * wtq + q0) << 6) + lane) * 4
+                    : P(SD_W) + (long)nc[c] * I(SD_LDW) + q0 * 16 + lg * 4;
 
     f32x4 acc[16];
 #pragma unroll
@@ -482,6 +506,7 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
     constexpr int RPW = NREG >= W ? NREG / W : 1;   // registers finished by each (active) wave
     const bool active = wave * RPW < NREG;          // (1,1) with 8 waves: waves 4..7 only contribute partial sums
     float e_add[RPW], e_cls[RPW];
+    const int add1_tw = I(SD_ADD1_TW), out_tw = I(SD_OUT_TW), pre_tw = I(SD_PRE_TW);
     auto epilogue_operands = [&]() {
         if (!active) return;
 #pragma unroll
@@ -492,7 +517,8 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
             const int rowc = row < M ? row : 0;
             const int ncol = nc[cb];
             const float t0 = P(SD_BIAS)[ncol];
-            const float t1 = P(SD_ADD1)[(long)(rowc >> I(SD_ADD1_SHIFT)) * I(SD_ADD1_STRIDE) + ncol];
+            const long i1 = (long)(rowc >> I(SD_ADD1_SHIFT)) * I(SD_ADD1_STRIDE) + ncol;
+            const float t1 = P(SD_ADD1)[add1_tw ? tiled_index(i1, add1_tw) : i1];
             const float t2 = P(SD_ADD2)[(long)(rowc >> I(SD_ADD2_SHIFT)) * I(SD_ADD2_STRIDE) + ncol];
             const float t3 = P(SD_ADD3)[(long)rowc * I(SD_ADD3_STRIDE) + ncol];
             const int cls_ld = I(SD_CLS_LD);
@@ -508,7 +534,7 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
         auto phase1 = [&](auto cnt_c) {
             constexpr int CNT = decltype(cnt_c)::value;
 #pragma unroll
-            for (int u = 0; u < CNT; ++u) skinny16_load_step<RB, CB>(ap, bp, u, a[u], b[u]);
+            for (int u = 0; u < CNT; ++u) skinny16_load_step<RB, CB>(ap, bp, u, astep, bstep, a[u], b[u]);
         };
         auto phase2 = [&](auto cnt_c) {
             constexpr int CNT = decltype(cnt_c)::value;
@@ -542,10 +568,10 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
         for (int u = 0; u < 4; ++u)
             if (u < cnt) {
 #pragma unroll
-                for (int c = 0; c < CB; ++c) b[u][c] = *reinterpret_cast<gcf4 *>(bp[c] + u * 16);
+                for (int c = 0; c < CB; ++c) b[u][c] = *reinterpret_cast<gcf4 *>(bp[c] + u * bstep);
                 if (u < 2) {
 #pragma unroll
-                    for (int r = 0; r < RB; ++r) a[u][r] = *reinterpret_cast<gcf4 *>(ap[r] + u * 16);
+                    for (int r = 0; r < RB; ++r) a[u][r] = *reinterpret_cast<gcf4 *>(ap[r] + u * astep);
                 }
             }
         __builtin_amdgcn_sched_barrier(0);
@@ -556,7 +582,7 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
                 skinny16_mfma_step<RB, CB>(a[u & 1], b[u], acc);
                 if (u + 2 < cnt) {
 #pragma unroll
-                    for (int r = 0; r < RB; ++r) a[u & 1][r] = *reinterpret_cast<gcf4 *>(ap[r] + (u + 2) * 16);
+                    for (int r = 0; r < RB; ++r) a[u & 1][r] = *reinterpret_cast<gcf4 *>(ap[r] + (u + 2) * astep);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // keep step u's MFMAs ahead of the waits of step u+1
             }
@@ -588,7 +614,10 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
         const bool ok = n_ok[cb] && row < M;
         v += e_add[rr];
         if (gate) {
-            if ((flags & SDF_PRE) && ok) ((gf *)P(SD_PRE))[(long)row * I(SD_PRE_STRIDE) + n[cb]] = v;
+            if ((flags & SDF_PRE) && ok) {
+                const long ip = (long)row * I(SD_PRE_STRIDE) + n[cb];
+                ((gf *)P(SD_PRE))[pre_tw ? tiled_index(ip, pre_tw) : ip] = v;
+            }
             v += e_cls[rr];
             const float partner = __shfl_xor(v, 8);
             if ((li & 8) == 0 && ok) {
@@ -596,11 +625,15 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
                 const int t16 = tile * CB + cb;
                 const int tiles_per_group = gateD >> 3;
                 const int group = t16 / tiles_per_group, ch0 = (t16 - group * tiles_per_group) << 3;
-                out[(long)row * out_stride + group * gateD + ch0 + (li & 7)] = g;
+                const long io = (long)row * out_stride + group * gateD + ch0 + (li & 7);
+                out[out_tw ? tiled_index(io, out_tw) : io] = g;
             }
         } else {
             if (flags & SDF_RELU) v = v > 0.f ? v : 0.f;
-            if (ok) out[(long)row * out_stride + n[cb]] = v;
+            if (ok) {
+                const long io = (long)row * out_stride + n[cb];
+                out[out_tw ? tiled_index(io, out_tw) : io] = v;
+            }
         }
     }
     if (TRACE && tid == 0) {
@@ -690,16 +723,25 @@ static bool skinny_pack_desc(const SkinnyParams &p, int W, const float *zero, Sk
     put_ptr(d, SD_PRE, p.pre);
     d.w[SD_PRE_STRIDE] = (uint32_t)p.pre_stride;
     put_ptr(d, SD_ZERO, zero);
+    auto lg2 = [](int w) { int l = 0; while ((1 << l) < w) ++l; return (w >= 16 && (1 << l) == w) ? l : -1; };
+    if (p.w_tiled) {
+        if (p.w_tiled * 16 != p.Ktot) return false;
+        d.w[SD_WTQ] = p.w_tiled;
+    }
+    if (p.out_tiled_w) { if (lg2(p.out_tiled_w) < 0) return false; d.w[SD_OUT_TW] = lg2(p.out_tiled_w); }
+    if (p.pre_tiled_w) { if (lg2(p.pre_tiled_w) < 0) return false; d.w[SD_PRE_TW] = lg2(p.pre_tiled_w); }
+    if (p.add1_tiled_w) { if (lg2(p.add1_tiled_w) < 0 || p.add1_shift) return false; d.w[SD_ADD1_TW] = lg2(p.add1_tiled_w); }
     for (int s = 0; s < p.nseg; ++s) {
         const SkinnySeg &sg = p.seg[s];
-        if (sg.len % (16 * cnt) != 0 || !fits_i32(sg.row_stride) || !fits_i32(sg.gidx_stride)) return false;
+        if (sg.len % (16 * cnt) != 0 || !fits_i32(sg.row_stride) || !fits_i32(sg.gidx_stride) || sg.row_shift != 0) return false;
+        if (sg.tiled_w && (sg.gidx || !sg.base || sg.tiled_w % 16 || sg.tiled_w / 16 > 0xffff || sg.len != sg.tiled_w)) return false;
         const int k = SD_SEG + s * SD_SEG_WORDS;
         const bool zero_rows = !sg.gidx && !sg.base;   // null dense segment = rows of zeros
         put_ptr(d, k, zero_rows ? zero : sg.base);
         put_ptr(d, k + 2, sg.gidx);
         d.w[k + 4] = zero_rows ? 0 : (uint32_t)sg.row_stride;
         d.w[k + 5] = (uint32_t)sg.gidx_stride;
-        d.w[k + 6] = zero_rows ? 0 : sg.row_shift;
+        d.w[k + 6] = sg.tiled_w ? (SEG_TILED | (sg.tiled_w / 16)) : 0;
         d.w[k + 7] = sg.len / 16;
     }
     return true;
@@ -828,6 +870,12 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
                 return hipGetLastError();
             }
         }
+        for (int i = 0; i < n; ++i) {   // the generic kernels read row-major operands only
+            const SkinnyParams &q = b.p[i];
+            bool tiled = q.w_tiled || q.out_tiled_w || q.pre_tiled_w || q.add1_tiled_w;
+            for (int sgi = 0; sgi < q.nseg; ++sgi) tiled = tiled || q.seg[sgi].tiled_w;
+            if (tiled) return hipErrorInvalidValue;
+        }
         if (W16 == 8) hipLaunchKernelGGL(skinny16_kernel<8>, grid, dim3(512), 0, stream, b);
         else hipLaunchKernelGGL(skinny16_kernel<4>, grid, dim3(256), 0, stream, b);
         return hipGetLastError();
@@ -849,6 +897,33 @@ int skinny_trace_read(unsigned long long *out, int max_records) {
     if (n && hipMemcpy(out, t, n * TRACE_REC * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     if (hipMemset(t, 0, TRACE_SLOTS * TRACE_REC * sizeof(unsigned long long)) != hipSuccess) return -1;
     return (int)n;   // slots (launch-major); empty slots are all zero
+}
+
+void skinny_tile_weights(const float *W, int N, int K, long ldw, int epi, int gateD, float *out) {
+    const int nt = (N + 15) / 16, Q = K / 16;
+    for (int t = 0; t < nt; ++t)
+        for (int li = 0; li < 16; ++li) {
+            int n;
+            if (epi == EPI_GATE) {   // same column order as the kernel's gate tiles
+                const int tiles_per_group = gateD >> 3;
+                const int group = t / tiles_per_group, ch0 = (t - group * tiles_per_group) << 3;
+                n = group * 2 * gateD + (li >> 3) * gateD + ch0 + (li & 7);
+            } else {
+                n = t * 16 + li;
+            }
+            for (int q = 0; q < Q; ++q)
+                for (int lg = 0; lg < 4; ++lg)
+                    for (int e = 0; e < 4; ++e)
+                        out[(((size_t)t * Q + q) * 64 + li + 16 * lg) * 4 + e] = n < N ? W[(size_t)n * ldw + 16 * q + 4 * lg + e] : 0.f;
+        }
+}
+
+bool skinny_descriptor_kernel_enabled() {
+    const char *v = getenv("TS_SKINNY_V"), *nt = getenv("TS_SKINNY_NT"), *t = getenv("TS_SKINNY_TILED");
+    if (v && atoi(v) == 0) return false;
+    if (nt && atoi(nt) == 32) return false;
+    if (t && atoi(t) == 0) return false;
+    return true;
 }
 
 hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream) {
