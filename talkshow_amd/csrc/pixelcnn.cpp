@@ -65,6 +65,7 @@ struct ts_pixelcnn {
     ConvLayer aud_h1;                                        // Wh1_1 applied to AEH for every row (l = 1 has AEH in place of XH_0)
     bool use_graph = true;
     bool pair_vh = true;
+    int defer_p = -1;     // the next-row projections P_l of the vertical stack ride with column 1's launches: -1 auto, 0 never, 1 always
     // tiled operand layouts (kernels.h, SkinnyParams::w_tiled): every weight matrix of the chain gets a tiled twin, and
     // the activation buffers that feed the next stage's GEMM (OV0, XV, HV, G, XH, Y) are written / read tiled
     bool tiled = false;
@@ -251,7 +252,8 @@ int launch_slot(ts_pixelcnn *p, ts_pixelcnn::Work *w, const Slot &a, const Slot 
 }
 
 // vertical stack + v->h projections of row r as NL+2 launch slots
-void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &out) {
+// `deferred` (optional): the P_l problems (only read by row r+1) are handed back instead of riding in slot V_l
+void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &out, std::vector<SkinnyParams> *deferred = nullptr) {
     const int B = c.B, D = p->D, NL = p->NL, R = c.R;
     ts_pixelcnn::Work *w = c.w;
     const int *tok = w->tok32.i();
@@ -358,7 +360,8 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
             }
             q.out = P(l, (r + 1) & 1);
             q.out_stride = 4 * D;
-            s.add(q);
+            if (deferred) deferred->push_back(q);
+            else s.add(q);
         }
         s.add(make_v2h(l - 1));
         out.push_back(s);
@@ -512,7 +515,12 @@ int launch_sampler(ts_pixelcnn *p, const RunCfg &c, int r, int j, hipStream_t s)
 
 int run_row(ts_pixelcnn *p, const RunCfg &c, int r, bool need_h, hipStream_t s) {
     std::vector<Slot> V, H;
-    build_vertical(p, c, r, V);
+    // Up to 128 clips the column-0 launches (vertical slot riding with the horizontal one) come to 272 workgroups at every
+    // tile shape — 16 more than CUs, and the 16 doubled-up CUs set the launch time (5.9 vs 3.6 us at 32 clips).  The P_l
+    // projections are only read by the next row: there they ride with column 1's launches (96 -> 160 workgroups).
+    std::vector<SkinnyParams> Pd;
+    const bool defer = need_h && p->pair_vh && (p->defer_p < 0 ? c.B <= 128 : p->defer_p > 0);
+    build_vertical(p, c, r, V, defer ? &Pd : nullptr);
     if (!need_h) {
         for (auto &sl : V) TS_TRY(launch_slot(p, c.w, sl, nullptr, s));
         return 0;
@@ -534,7 +542,14 @@ int run_row(ts_pixelcnn *p, const RunCfg &c, int r, bool need_h, hipStream_t s) 
     }
     TS_TRY(launch_sampler(p, c, r, 0, s));
     build_horizontal(p, c, r, 1, H);
-    for (auto &sl : H) TS_TRY(launch_slot(p, c.w, sl, nullptr, s));
+    size_t pi = 0;
+    for (size_t k = 0; k < H.size(); ++k) {
+        Slot ride;
+        // the last horizontal slots take what is left, so that every P_l has run before the row ends
+        while (pi < Pd.size() && H[k].n + ride.n < SKINNY_MAX_PROBLEMS && (ride.n == 0 || Pd.size() - pi > H.size() - 1 - k)) ride.add(Pd[pi++]);
+        TS_TRY(launch_slot(p, c.w, H[k], ride.n ? &ride : nullptr, s));
+    }
+    if (pi < Pd.size()) return fail("pixelcnn: deferred projections left over");
     return launch_sampler(p, c, r, 1, s);
 }
 
@@ -788,6 +803,7 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
         TS_TRY(tile(p->w2, V, p->HID, p->HID, EPI_LINEAR, 0));
     }
     if (const char *e = std::getenv("TS_NO_GRAPH")) p->use_graph = !(e[0] && e[0] != '0');
+    if (const char *e = std::getenv("TS_PIX_DEFER_P")) p->defer_p = std::atoi(e);
     if (const char *e = std::getenv("TS_NO_PAIR")) p->pair_vh = !(e[0] && e[0] != '0');
     *out = p.release();
     return 0;

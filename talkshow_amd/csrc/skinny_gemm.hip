@@ -412,8 +412,11 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
     // with a private L2.  Workgroup id b is given logical tile (b % 8) * (n / 8) + b / 8, so that one XCD owns a
     // CONTIGUOUS eighth of the (problem, column tile) space: it pulls only its eighth of the stage's weights through the
     // fabric and its row tiles re-read them from its own L2 (tiles are enumerated column-major inside a problem).
+    // start[6] & 2 — the balanced form: every PROBLEM's column tiles are dealt over the XCDs (column tile c belongs to XCD
+    // c % 8), so each XCD gets an eighth of every problem (problems differ in K) and still pulls only an eighth of the weights.
     int bx = blockIdx.x;
-    if (batch.start[6] & 1) {
+    const int xmode = batch.start[6];
+    if (xmode & 1) {
         const int per = (int)gridDim.x >> 3;
         if (bx < per * 8) bx = (bx & 7) * per + (bx >> 3);
     }
@@ -433,7 +436,15 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
     };
     const int M = I(SD_M), N = I(SD_N), flags = I(SD_FLAGS), gateD = I(SD_GATED);
     const int nmt = (M + ROWS - 1) / ROWS;      // row tiles; tiles of a problem are enumerated column-major
-    const int tile = (bx - first) / nmt, mt = (bx - first) - tile * nmt;
+    int tile, mt;
+    if (xmode & 2) {   // host guarantees: every problem starts at a multiple of 8 and has a multiple of 8 column tiles
+        const int t = bx - first, sl = t >> 3, tl = sl / nmt;
+        mt = sl - tl * nmt;
+        tile = tl * 8 + (t & 7);
+    } else {
+        tile = (bx - first) / nmt;
+        mt = (bx - first) - tile * nmt;
+    }
     if (TRACE) tr[1] = wall_clock64();
 
     const bool gate = flags & SDF_GATE;
@@ -832,7 +843,11 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
             int total = 0;
             for (int i = 0; i < 8; ++i) db.start[i] = 0x7fffffff;
             static const int xcd_min = [] { const char *e = getenv("TS_SKINNY_XCD_MIN_M"); return e ? atoi(e) : (1 << 30); }();
-            db.start[6] = maxM >= xcd_min ? 1 : 0;     // XCD-aware tile order: measured SLOWER (M = 256: 52.8 vs 45.2 ms per pass), off
+            static const int xcd_mode = [] { const char *e = getenv("TS_SKINNY_XCD_MODE"); return e ? atoi(e) : 2; }();
+            bool by8 = true;
+            for (int i = 0; i < n; ++i)
+                if ((b.p[i].grid_x / CB) % 8) by8 = false;
+            db.start[6] = maxM >= xcd_min ? (xcd_mode == 2 ? (by8 ? 2 : 0) : 1) : 0;
             for (int i = 0; i < n && fast; ++i) {
                 fast = skinny_pack_desc(b.p[i], W16, g_zero[dev], db.d[i]);
                 db.start[i] = total;
