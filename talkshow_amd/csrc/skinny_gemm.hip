@@ -436,13 +436,18 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
     };
     const int M = I(SD_M), N = I(SD_N), flags = I(SD_FLAGS), gateD = I(SD_GATED);
     const int nmt = (M + ROWS - 1) / ROWS;      // row tiles; tiles of a problem are enumerated column-major
+    // scalar integer division costs ~30 instructions on the way to the first operand load: the usual divisors (row tiles per
+    // problem, gate tiles per group, class-row width) are powers of two.  Same-box A/B: 37.1 -> 36.4 ms per 256-clip pass.
+    // (The instruction stream ahead of the loads is worth ~0.1 us per 100 instructions here — and removing the dead `xmode & 1`
+    // branch below or fetching start[] with one scalar load made the launch 4 % SLOWER, twice: code layout, not logic.)
+    auto sdiv = [](int x, int d) { return (d & (d - 1)) == 0 ? x >> __builtin_ctz(d) : x / d; };
     int tile, mt;
     if (xmode & 2) {   // host guarantees: every problem starts at a multiple of 8 and has a multiple of 8 column tiles
-        const int t = bx - first, sl = t >> 3, tl = sl / nmt;
+        const int t = bx - first, sl = t >> 3, tl = sdiv(sl, nmt);
         mt = sl - tl * nmt;
         tile = tl * 8 + (t & 7);
     } else {
-        tile = (bx - first) / nmt;
+        tile = sdiv(bx - first, nmt);
         mt = (bx - first) - tile * nmt;
     }
     if (TRACE) tr[1] = wall_clock64();
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
         const int t16 = tile * CB + c;
         if (gate) {
             const int tiles_per_group = gateD >> 3;
-            const int group = t16 / tiles_per_group, ch0 = (t16 - group * tiles_per_group) << 3;
+            const int group = sdiv(t16, tiles_per_group), ch0 = (t16 - group * tiles_per_group) << 3;
             n[c] = group * 2 * gateD + (li >> 3) * gateD + ch0 + (li & 7);
         } else {
             n[c] = t16 * 16 + li;
@@ -533,7 +538,8 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
             const float t2 = P(SD_ADD2)[(long)(rowc >> I(SD_ADD2_SHIFT)) * I(SD_ADD2_STRIDE) + ncol];
             const float t3 = P(SD_ADD3)[(long)rowc * I(SD_ADD3_STRIDE) + ncol];
             const int cls_ld = I(SD_CLS_LD);
-            e_cls[rr] = P(SD_CLS)[(long)rowc * cls_ld + (ncol % cls_ld)];
+            const int ccol = (cls_ld & (cls_ld - 1)) == 0 ? (ncol & (cls_ld - 1)) : ncol % cls_ld;
+            e_cls[rr] = P(SD_CLS)[(long)rowc * cls_ld + ccol];
             e_add[rr] = ((t0 + t1) + t2) + t3;
         }
     };
@@ -635,7 +641,7 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
                 const float g = tanhf(v) * (1.0f / (1.0f + expf(-partner)));
                 const int t16 = tile * CB + cb;
                 const int tiles_per_group = gateD >> 3;
-                const int group = t16 / tiles_per_group, ch0 = (t16 - group * tiles_per_group) << 3;
+                const int group = sdiv(t16, tiles_per_group), ch0 = (t16 - group * tiles_per_group) << 3;
                 const long io = (long)row * out_stride + group * gateD + ch0 + (li & 7);
                 out[out_tw ? tiled_index(io, out_tw) : io] = g;
             }
