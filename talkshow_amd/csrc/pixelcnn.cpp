@@ -295,7 +295,7 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
         Slot s;
         SkinnyParams g = base_params(B, 4 * D, EPI_GATE);
         if (r >= 1) emb_row(g, r - 1);
-        else add_dense(g, nullptr, 0, 0, 128);   // top row: bias + conditioning only (a zero segment keeps it on the descriptor kernel)
+        else add_dense(g, nullptr, 0, 0, std::min(128, 2 * D));   // top row: bias + conditioning only (a zero segment keeps it on the descriptor kernel)
         g.W = p->wvt[0][2]->f();
         g.bias = p->bv[0]->f();
         if (r >= 2) {
@@ -398,7 +398,7 @@ void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector
         Slot s;
         SkinnyParams q = base_params(B, 2 * D, EPI_GATE);
         if (j == 1) add_gather(q, p->emb.f(), D, tok + (size_t)(r % R) * 2 + 0, (long)R * 2, D);
-        else add_dense(q, nullptr, 0, 0, 128);   // column 0 has nothing to its left: a block of zero rows keeps the launch on
+        else add_dense(q, nullptr, 0, 0, std::min(128, 2 * D));   // column 0 has nothing to its left: a block of zero rows keeps the launch on
                                                  // the descriptor kernel (K = 0 would drop the whole launch to the generic one)
         q.W = p->wh[0]->f();
         q.ldw = 2 * D;

@@ -669,18 +669,23 @@ def test_device_mfcc_vs_host_restatement(hip, tmp_path):
 
 
 @pytest.mark.parametrize("env", [{"TS_SKINNY_V": "0"}, {"TS_NO_GRAPH": "1"}, {"TS_SKINNY_NT": "32"},
-                                 {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"}, {"TS_SKINNY_SHAPE": "44"}],
+                                 {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"}, {"TS_SKINNY_SHAPE": "44"},
+                                 {"TS_SKINNY_TILED": "0", "TS_WITH_CLIPS": "1"}, {"TS_PIX_DEFER_P": "0", "TS_WITH_CLIPS": "1"},
+                                 {"TS_PIX_DEFER_P": "1", "TS_WITH_CLIPS": "1"}, {"TS_SKINNY_XCD_MIN_M": "0", "TS_WITH_CLIPS": "1"}],
                          ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
-                              "tile_64x64"])
+                              "tile_64x64", "row_major_operands", "projections_in_column0", "projections_in_column1",
+                              "xcd_tile_order"])
 def test_alternate_kernel_paths(hip, env):
     """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
-    launches, the 32-column kernel).  The knobs are read once per process, so the golden-vector tests are re-run in a child
+    launches, the 32-column kernel), row-major instead of tiled operands, two placements of the next-row projections and an
+    XCD-aware tile order.  The knobs are read once per process, so the golden-vector tests are re-run in a child
     process with each fallback forced: all paths must stay bit-exact on the codes."""
     import subprocess
     import sys
     child_env = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q",
-                        "-k", "pixelcnn_golden or pixelcnn_sampling_and_prefix or single_layer_pixelcnn or op_linear"],
+                        "-k", "pixelcnn_golden or pixelcnn_sampling_and_prefix or single_layer_pixelcnn or op_linear"
+                        + (" or golden_clips" if env.get("TS_WITH_CLIPS") else "")],   # BASELINE-size batches: the coalesced tile shapes
                        env=child_env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

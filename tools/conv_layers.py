@@ -5,7 +5,7 @@ import torch, bench
 from talkshow_amd import _lib, synth
 lib=_lib.load(); w,_=bench.build_models(0)
 B,T=int(os.environ.get("TS_B","32")),300
-mfcc=torch.from_numpy(synth.mfcc_features(1000,B,T)).cuda(); gt=torch.from_numpy(synth.gt_poses(2000,B,T)).cuda(); ids=torch.from_numpy(synth.speaker_ids(B)).cuda()
+mfcc=torch.from_numpy(synth.mfcc_features(1000,B,T)).cuda(); gt=torch.from_numpy(synth.gt_poses(2000,B,T)).cuda()*float(os.environ.get("TS_GT_SCALE","1")); ids=torch.from_numpy(synth.speaker_ids(B)).cuda()
 codes=torch.empty((B,75,2),dtype=torch.int64,device="cuda")
 def step():
     _lib.check(lib.ts_body_vq_infer(w.g_body.handle(), w.g_hand.handle(), _lib.dptr(gt), B, T, _lib.dptr(codes), None, _lib.stream_ptr()))
