@@ -59,6 +59,11 @@ int ts_stream_create_cus(ts_ctx *ctx, int cu_first, int cu_count, void **out_str
 /* Tuning aid: with TS_SKINNY_TRACE=1 the chain kernel stamps the device wall clock (100 MHz) at five points; this reads
  * (and resets) the records, 6 uint64 each.  Returns the number of records or -1. */
 int ts_debug_skinny_trace(unsigned long long *out, int max_records);
+/* Host-only helper (no GPU needed): the TILED copy of a row-major weight matrix W[N][ldw] (K columns used) that the
+ * PixelCNN chain kernel multiplies with — every 16-column x 16-k operand fragment one contiguous KB in lane order
+ * (DESIGN.md §3/§4); epi 0 = linear column order, 1 = gate (8 tanh channels + their 8 sigmoid partners per tile,
+ * gateD channels per half).  out holds ceil(N/16) * (K/16) * 256 floats.  K % 16 == 0.  No reference counterpart. */
+int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int gateD, float *out);
 int ts_stream_destroy(ts_ctx *ctx, void *stream);
 
 /* ---- AudioEncoder(in_dim=64, num_hiddens, num_residual_layers, ·)  — vqvae_1d.py:11-34 ------------------ */

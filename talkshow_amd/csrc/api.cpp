@@ -60,6 +60,12 @@ int ts_debug_skinny_trace(unsigned long long *out, int max_records) {
     if (!out) return -1;
     return ts::skinny_trace_read(out, max_records);
 }
+int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int gateD, float *out) {
+    if (!W || !out || N < 1 || K < 16 || K % 16 || ldw < K) return fail("ts_debug_tile_weights: bad argument");
+    if (epi == ts::EPI_GATE && (gateD < 8 || gateD % 8 || N % (2 * gateD))) return fail("ts_debug_tile_weights: gate tiles need gateD % 8 == 0 and N % (2 gateD) == 0");
+    ts::skinny_tile_weights(W, N, K, ldw, epi, gateD, out);
+    return 0;
+}
 int ts_stream_destroy(ts_ctx *ctx, void *stream) {
     if (!ctx) return fail("ts_stream_destroy: null ctx");
     TS_HIP(hipStreamSynchronize((hipStream_t)stream));

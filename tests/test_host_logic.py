@@ -136,3 +136,48 @@ def test_pose_index_matches_reference_layout():
     from talkshow_amd.pose_index import c_index_3d
     g = np.load(os.path.join(REPO, "tests", "golden", "body_vq_e2e_full.npz"))
     np.testing.assert_array_equal(c_index_3d, g["c_index"])      # c_index_3d as the reference computes it
+
+
+def _tiled_index(m, k, W):
+    """kernels.h, SkinnyParams::w_tiled: float index of element (m, k) of a [rows][W] array stored as 16 x 16 fragments."""
+    return (((m >> 4) * (W >> 4) + (k >> 4)) << 8) + (((m & 15) + 16 * ((k & 15) >> 2)) << 2) + (k & 3)
+
+
+@pytest.mark.parametrize("N,K,ldw", [(16, 16, 16), (40, 64, 80), (512, 256, 512)])
+def test_tiled_weight_layout_linear(N, K, ldw):
+    """Host-side tiling of a chain weight matrix (no GPU): every element lands where the documented fragment formula says,
+    rows past N read as zero."""
+    import ctypes as C
+    from talkshow_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(N + K)
+    W = rng.standard_normal((N, ldw)).astype(np.float32)
+    nt = (N + 15) // 16
+    out = np.full(nt * (K // 16) * 256, np.nan, np.float32)
+    _lib.check(lib.ts_debug_tile_weights(W.ctypes.data_as(C.c_void_p), N, K, ldw, 0, 0, out.ctypes.data_as(C.c_void_p)))
+    n, k = np.meshgrid(np.arange(nt * 16), np.arange(K), indexing="ij")
+    want = np.where(n < N, W[np.minimum(n, N - 1), k], 0.0).astype(np.float32)
+    assert np.array_equal(out[_tiled_index(n, k, K)], want)
+    assert not np.isnan(out).any()                      # the formula is a bijection onto the buffer
+
+
+def test_tiled_weight_layout_gate():
+    """Gate tiles: tile t holds 8 'tanh' channels followed by their 8 'sigmoid' partners (columns c and c + gateD of a
+    2*gateD group), the pairing the epilogue's lane-xor-8 shuffle relies on."""
+    import ctypes as C
+    from talkshow_amd import _lib
+    lib = _lib.load()
+    gateD, groups, K = 24, 2, 32
+    N = 2 * gateD * groups
+    W = np.random.default_rng(3).standard_normal((N, K)).astype(np.float32)
+    out = np.empty((N // 16) * (K // 16) * 256, np.float32)
+    _lib.check(lib.ts_debug_tile_weights(W.ctypes.data_as(C.c_void_p), N, K, K, 1, gateD, out.ctypes.data_as(C.c_void_p)))
+    tiles_per_group = gateD // 8
+    for t in range(N // 16):
+        group, ch0 = divmod(t, tiles_per_group)
+        for li in range(16):
+            col = group * 2 * gateD + (li >> 3) * gateD + ch0 * 8 + (li & 7)
+            got = out[_tiled_index(t * 16 + li, np.arange(K), K)]
+            assert np.array_equal(got, W[col]), (t, li)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        _lib.check(lib.ts_debug_tile_weights(W.ctypes.data_as(C.c_void_p), N, 24, K, 0, 0, out.ctypes.data_as(C.c_void_p)))
