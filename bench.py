@@ -449,8 +449,11 @@ def main():
 
     torch.cuda.synchronize()
     eng.warm(a.steps)
-    eng.run_steps(max(a.warmup, 1))                    # W untimed steps (passes of sizes the warm-up above has seen or captures now)
+    _, wposes = eng.run_steps(max(a.warmup, 1))       # W untimed steps (passes of sizes the warm-up above has seen or captures now)
     torch.cuda.synchronize()
+    if world > 1:
+        gather_sequences(wposes[-B:])                  # the exchange once untimed: RCCL sets up its rings / buffers on first use
+        torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     codes, poses = eng.run_steps(a.steps)
