@@ -4,11 +4,19 @@ Same exported names; the body path (`s2g_body_pixel`, `s2g_body_vq`), the face g
 (`s2g_body_ae`) run on libtalkshow_hip.so.  The one component the scope leaves out — the Habibie et al.
 baseline `LS3DCG` — raises `NotImplementedError` when constructed, naming the reason.
 """
-from .smplx_face import TrainWrapper as s2g_face
-from .smplx_body_vq import TrainWrapper as s2g_body_vq
-from .smplx_body_pixel import TrainWrapper as s2g_body_pixel
-from .body_ae import TrainWrapper as s2g_body_ae
-from .out_of_scope import LS3DCG
-from .base import TrainWrapperBaseClass
+from importlib import import_module as _import
 
-from .utils import normalize, denormalize
+# exported name -> (module of this package, attribute): the names `nets.init_model` and the reference's scripts look up
+_EXPORTS = {
+    "s2g_face": ("smplx_face", "TrainWrapper"),
+    "s2g_body_vq": ("smplx_body_vq", "TrainWrapper"),
+    "s2g_body_pixel": ("smplx_body_pixel", "TrainWrapper"),
+    "s2g_body_ae": ("body_ae", "TrainWrapper"),
+    "LS3DCG": ("out_of_scope", "LS3DCG"),
+    "TrainWrapperBaseClass": ("base", "TrainWrapperBaseClass"),
+    "normalize": ("utils", "normalize"),
+    "denormalize": ("utils", "denormalize"),
+}
+for _name, (_mod, _attr) in _EXPORTS.items():
+    globals()[_name] = getattr(_import(f"{__name__}.{_mod}"), _attr)
+__all__ = sorted(_EXPORTS)
