@@ -181,3 +181,14 @@ def test_tiled_weight_layout_gate():
             assert np.array_equal(got, W[col]), (t, li)
     with pytest.raises(RuntimeError, match="bad argument"):
         _lib.check(lib.ts_debug_tile_weights(W.ctypes.data_as(C.c_void_p), N, 24, K, 0, 0, out.ctypes.data_as(C.c_void_p)))
+
+
+def test_bench_pass_plan():
+    """bench.py groups the queued 32-clip steps into chain passes: full passes of G batches, then the remainder — the
+    driver's `--steps 20` at G = 8 is 8 + 8 + 4, every step is run exactly once."""
+    import bench
+    eng = bench.Engine.__new__(bench.Engine)
+    for G, steps, want in ((8, 20, [8, 8, 4]), (8, 48, [8] * 6), (16, 20, [16, 4]), (8, 5, [5]), (1, 3, [1, 1, 1])):
+        eng.G = G
+        assert eng.plan(steps) == want and sum(eng.plan(steps)) == steps
+    assert bench.FRAMES_PER_CLIP == 300
