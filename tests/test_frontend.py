@@ -3,7 +3,9 @@ run, so the restatement is pinned stage by stage against the INSTALLED third-par
 definitions: the STFT / power stage against `torch.stft` (the function torchaudio.transforms.Spectrogram calls), the
 HTK mel filterbank and the dB / top_db stage against `transformers.audio_utils` (HF's port of the torchaudio / librosa
 definitions), the DCT-II table against `scipy.fft.dct`, and the whole MFCC against a pipeline assembled from those
-pieces.  The sinc-Hann resampler has no installed counterpart: checked on closed-form properties only (UNPINNED)."""
+pieces.  The two resamplers have no installed counterpart (UNPINNED against torchaudio / resampy themselves): their
+indexing, phases, padding and length rules are checked against the continuous-time formulas they implement, evaluated
+directly in float64, and on closed-form signals."""
 import math
 import os
 
@@ -171,3 +173,44 @@ def test_get_wav16_resamples_other_rates(tmp_path):
     assert w.shape == (16000, 1) and w.dtype == np.float32
     ref = 0.75 * (20000 / 32768.0) * np.sin(2 * np.pi * 300 * np.arange(16000) / 16000.0)
     assert np.abs(w[400:-400, 0] - ref[400:-400]).max() < 2e-3
+
+
+@pytest.mark.parametrize("orig,new,n", [(16000, 22000, 1601), (22000, 16000, 2203), (48000, 16000, 4000), (8000, 22050, 333)])
+def test_sinc_hann_resampler_against_its_continuous_definition(orig, new, n):
+    """The polyphase / strided-window implementation (what torchaudio does, and what the device kernel mirrors) against the
+    formula it implements, evaluated directly in float64 with no phases, padding or windows of samples:
+        y[j] = sum_n x[n] * (f/orig) * sinc(t) * cos^2(pi t / (2 L)),  t = (n/orig - j/new) * f,  |t| < L = 6,
+        f = 0.99 * min(orig, new)   (rates reduced by their gcd first).
+    Pins the indexing (phase offsets, left padding, output length); the formula itself is the restated third-party part."""
+    rng = np.random.default_rng(orig + new)
+    x = rng.standard_normal(n).astype(np.float32)
+    y = fe.resample_sinc_hann(x[None], orig, new)[0]
+    g = math.gcd(orig, new)
+    o, w, L = orig // g, new // g, 6
+    f = min(o, w) * 0.99
+    assert y.shape[0] == math.ceil(w * n / o)
+    j = np.arange(y.shape[0], dtype=np.float64)[:, None]
+    k = np.arange(n, dtype=np.float64)[None, :]
+    t = (k / o - j / w) * f
+    kern = np.where(np.abs(t) < L, np.sinc(t) * np.cos(np.pi * t / (2 * L)) ** 2, 0.0) * (f / o)
+    want = kern @ x.astype(np.float64)
+    np.testing.assert_allclose(y, want, atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("orig,n", [(8000, 1500), (11025, 1700), (12000, 999)])
+def test_kaiser_best_interpolation_against_its_continuous_definition(orig, n):
+    """Up-sampling to 16 kHz (unit filter scale: no index_step truncation) against the band-limited interpolation formula
+    evaluated directly in float64 from the CLOSED-FORM window, y[j] = sum_n x[n] h(|j/ratio - n|), |.| < 64 zero crossings:
+    pins the table lookup, the linear interpolation between table entries, both wings and the edge limits."""
+    from scipy.special import i0
+    rng = np.random.default_rng(orig)
+    x = rng.standard_normal(n).astype(np.float32)
+    y = fe.resample_kaiser_best(x, orig, 16000)
+    ratio = 16000.0 / orig
+    n_out = int(n * ratio)
+    rolloff, beta = 0.9475937167399596, 14.769656459379492
+    t = np.abs(np.arange(n_out, dtype=np.float64)[:, None] / ratio - np.arange(n, dtype=np.float64)[None, :])
+    h = np.where(t < 64.0, rolloff * np.sinc(rolloff * t) * i0(beta * np.sqrt(np.maximum(0.0, 1.0 - (t / 64.0) ** 2))) / i0(beta), 0.0)
+    want = h @ x.astype(np.float64)
+    np.testing.assert_allclose(y[:n_out], want, atol=3e-5, rtol=0)
+    assert y.shape[0] == math.ceil(n * ratio) and np.all(y[n_out:] == 0)       # librosa's fix_length zero-fills the tail
