@@ -20,11 +20,11 @@
 #include <cstdint>
 
 #include "kernels.h"
+#include "skinny_desc.h"
 
 namespace ts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int W>
 __global__ __launch_bounds__(W * 64) void skinny_gemm_kernel(const SkinnyBatch batch) {
@@ -315,43 +315,6 @@ __global__ __launch_bounds__(W * 64) void skinny16_kernel(const SkinnyBatch batc
 //   * a wave's share of K is CNT = K / (16 W) <= 4 q-steps inside one segment (host-checked), straight-line code.
 // Partition of K over waves and the LDS summation order are those of skinny16_kernel: results are bit-identical.
 // ---------------------------------------------------------------------------------------------------------------
-enum {   // descriptor word indices
-    SD_M = 0, SD_N, SD_CNT, SD_FLAGS, SD_GATED, SD_GX, SD_GY, SD_NSEG,
-    SD_W = 8, SD_LDW = 10, SD_BIAS = 11,
-    SD_ADD1 = 13, SD_ADD1_STRIDE = 15, SD_ADD1_SHIFT = 16,
-    SD_ADD2 = 17, SD_ADD2_STRIDE = 19, SD_ADD2_SHIFT = 20,
-    SD_ADD3 = 21, SD_ADD3_STRIDE = 23,
-    SD_CLS = 24, SD_CLS_LD = 26,
-    SD_OUT = 27, SD_OUT_STRIDE = 29, SD_PRE = 30, SD_PRE_STRIDE = 32,
-    SD_SEG = 33,   // per segment: base(2) gidx(2) row_stride gidx_stride row_shift len16
-    SD_SEG_WORDS = 8,
-    SD_ZERO = 57,
-    SD_WTQ = 59,       // K / 16 when the weights are tiled, else 0
-    SD_OUT_TW = 60,    // log2 of the tiled view width of out / pre / add1, or 0 (row-major)
-    SD_PRE_TW = 61,
-    SD_ADD1_TW = 62,
-};
-enum { SDF_GATE = 1, SDF_RELU = 2, SDF_PRE = 4 };
-constexpr int SEG_TILED = 0x10000;   // segment word 6: SEG_TILED | (W / 16) for a tiled dense segment
-
-// float index of element `lin` (= row * row_width + col) of a buffer tiled with view width 2^lw
-__device__ __forceinline__ long tiled_index(long lin, int lw) {
-    const long m = lin >> lw;
-    const int k = (int)(lin - (m << lw));
-    return ((((m >> 4) << (lw - 4)) + (k >> 4)) << 8) + ((int)((m & 15) + (((k & 15) >> 2) << 4)) << 2) + (k & 3);
-}
-struct SkinnyDesc { uint32_t w[64]; };
-struct SkinnyDescBatch {
-    int start[8];   // first workgroup of problem i (1-D grid over live tiles only); INT_MAX for unused problems
-    SkinnyDesc d[SKINNY_MAX_PROBLEMS];
-};
-
-// descriptor pointers are rebuilt from integers: tag them as global (address space 1) so the loads are global_load, not flat
-typedef __attribute__((address_space(1))) const float gcf;
-typedef __attribute__((address_space(1))) float gf;
-typedef __attribute__((address_space(1))) const int gci;
-typedef __attribute__((address_space(1))) const f32x4 gcf4;
-
 template <int V> struct IC { static constexpr int value = V; };
 
 // One q-step (16 k) of a wave: RB row blocks x CB column blocks of 16x16 outputs share RB + CB 16-byte operand loads.
@@ -380,7 +343,8 @@ constexpr unsigned TRACE_WGS = 512;          // slots per launch
 constexpr unsigned TRACE_LAUNCHES = 4096;    // launches traced (launch sequence number modulo this)
 constexpr size_t TRACE_SLOTS = (size_t)TRACE_WGS * TRACE_LAUNCHES;
 __device__ unsigned long long *g_trace;   // [TRACE_SLOTS][TRACE_REC], allocated by skinny_init when TS_SKINNY_TRACE is set
-static unsigned g_trace_seq = 0;          // host: sequence number handed to the next traced launch
+static unsigned g_trace_seq = 0;
+static unsigned long long *g_trace_host = nullptr;   // host copy of the device pointer in g_trace          // host: sequence number handed to the next traced launch
 
 // Tile = RB x CB blocks of 16 x 16 outputs (one v_mfma_f32_16x16x4_f32 accumulator each):
 //   (1,1) 16 rows x 16 columns   a single chain whose launch still fits one workgroup per CU: least bytes per CU
@@ -689,6 +653,7 @@ hipError_t skinny_init(int device) {   // called from ts_ctx_create (never durin
         if (e != hipSuccess) return e;
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &t, sizeof(t));
         if (e != hipSuccess) return e;
+        g_trace_host = t;
     }
     return hipSuccess;
 }
@@ -764,6 +729,33 @@ static bool skinny_pack_desc(const SkinnyParams &p, int W, const float *zero, Sk
     return true;
 }
 
+// the wide kernel's shape constraints; *Q = q-steps (16 k) of the problem, 0 for a block of zero rows (epilogue only)
+static bool skinny_wide_ok(const SkinnyParams &p, int W, int *Q) {
+    auto al16 = [](const void *q) { return ((uintptr_t)q & 15) == 0; };
+    if (p.M < 1 || p.N % 64 != 0) return false;
+    if (p.epi == EPI_GATE && (p.gateD % 8 != 0 || p.N % (2 * p.gateD) != 0)) return false;
+    if (!al16(p.bias) || !al16(p.add1) || !al16(p.add2) || !al16(p.add3) || !al16(p.out) || !al16(p.pre)) return false;
+    if ((p.add1 && p.add1_stride % 4) || (p.add2 && p.add2_stride % 4) || (p.add3 && p.add3_stride % 4) || p.out_stride % 4 ||
+        (p.pre && p.pre_stride % 4))
+        return false;
+    if (p.epi == EPI_GATE && p.clsrow && (p.cls_ld % 4 || !al16(p.clsrow))) return false;
+    if (p.nseg == 1 && !p.seg[0].gidx && !p.seg[0].base) {
+        *Q = 0;
+        return true;
+    }
+    if (!p.w_tiled || p.Ktot % 64 != 0 || p.Ktot % (16 * W) != 0) return false;
+    const int cnt = p.Ktot / (16 * W);
+    if (cnt != 2 && cnt != 4) return false;
+    for (int s = 0; s < p.nseg; ++s) {
+        const SkinnySeg &sg = p.seg[s];
+        if (sg.len % 64 != 0 || !al16(sg.base)) return false;
+        if (!sg.tiled_w && sg.row_stride % 4 != 0) return false;
+        if (!sg.gidx && !sg.base) return false;   // zero rows inside a real problem: not needed, not supported
+    }
+    *Q = p.Ktot / 16;
+    return true;
+}
+
 static int skinny_grid(SkinnyParams &p, int ncol) {
     if (p.Ktot % (ncol == 16 ? 16 : 8) != 0 || p.M <= 0) return -1;
     for (int s = 0; s < p.nseg; ++s)
@@ -808,6 +800,51 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
         if (variant != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_zero[dev]) {
             SkinnyDescBatch db;
             bool fast = true;
+            // ---- wide path (skinny_wide.hip): a coalesced pass whose launch fills the chip with 64 x 64 full-K tiles ----
+            static const int wide_min = [] { const char *e = getenv("TS_SKINNY_WIDE_MIN"); return e ? atoi(e) : 160; }();
+            {
+                int wM = 0, Qmax = 0, Qp[SKINNY_MAX_PROBLEMS];
+                bool wide = wide_min > 0;
+                for (int i = 0; i < n && wide; ++i) {
+                    wM = wM > b.p[i].M ? wM : b.p[i].M;
+                    wide = skinny_wide_ok(b.p[i], W16, &Qp[i]);
+                    Qmax = Qmax > Qp[i] ? Qmax : Qp[i];
+                }
+                if (wide && wM >= 64) {
+                    int total = 0, items[SKINNY_MAX_PROBLEMS];
+                    for (int i = 0; i < 8; ++i) db.start[i] = 0x7fffffff;
+                    for (int i = 0; i < n; ++i) {
+                        // a workgroup works through `items` tiles: problems with a fraction of the launch's biggest K get
+                        // several, so that every workgroup carries about the same work (an epilogue-only tile counts as 4 q-steps)
+                        const int cost = Qp[i] > 4 ? Qp[i] : 4;
+                        items[i] = Qmax / cost < 1 ? 1 : (Qmax / cost > 4 ? 4 : Qmax / cost);
+                        const int tiles = (b.p[i].N / 64) * ((b.p[i].M + 63) / 64);
+                        db.start[i] = total;
+                        total += (tiles + items[i] - 1) / items[i];
+                    }
+                    if (total >= wide_min) {
+                        for (int i = 0; i < n && wide; ++i) {
+                            wide = skinny_pack_desc(b.p[i], W16, g_zero[dev], db.d[i]);
+                            if (Qp[i] == 0) db.d[i].w[SD_WTQ] = 0, db.d[i].w[SD_NSEG] = 0;   // zero rows: epilogue only
+                            db.d[i].w[SD_ITEMS] = items[i];
+                        }
+                        for (int i = n; i < SKINNY_MAX_PROBLEMS; ++i) std::memset(&db.d[i], 0, sizeof(SkinnyDesc));
+                        if (wide) {
+                            db.start[6] = db.start[7] = 0;
+                            static const int wide_xcd = [] { const char *e = getenv("TS_SKINNY_WIDE_XCD"); return e ? atoi(e) : 0; }();
+                            db.start[0] = wide_xcd;   // launch flags (problem 0 always starts at workgroup 0)
+                            if (g_trace_host) {
+                                const uint64_t rec = (uint64_t)(uintptr_t)(g_trace_host + (size_t)(g_trace_seq++ % TRACE_LAUNCHES) * TRACE_WGS * TRACE_REC);
+                                db.start[6] = (int)(uint32_t)rec;
+                                db.start[7] = (int)(uint32_t)(rec >> 32);
+                            }
+                            static const int twice = [] { const char *e = getenv("TS_SKINNY_WIDE_TWICE"); return e ? atoi(e) : 0; }();
+                            if (twice) (void)launch_skinny_wide(db, total, stream, false);   // experiment: the 2nd launch finds its operands in L2
+                            return launch_skinny_wide(db, total, stream, g_trace_host != nullptr);
+                        }
+                    }
+                }
+            }
             // Tile shape (rows x columns in blocks of 16).  One batch (M <= 32): 16-row tiles when the launch then still
             // fits one workgroup per CU (less to fetch per CU), else 32 x 16.  Coalesced batches (M >= 64): the biggest of
             // 64 x 32 / 32 x 32 / 32 x 16 that still spreads the launch over about all CUs (fewer operand bytes per output).
