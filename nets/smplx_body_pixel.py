@@ -9,7 +9,7 @@ import torch
 from nets.base import TrainWrapperBaseClass, resolve_device
 from talkshow_amd import _lib
 from talkshow_amd.frontend import get_mfcc_sepa, get_mfcc_ta
-from talkshow_amd.modules import AudioEncoder, GatedPixelCNN as pixelcnn, VQVAE as s2g_body, _check_index_range
+from talkshow_amd.modules import AudioEncoder, GatedPixelCNN as pixelcnn, VQVAE as s2g_body, _index_tensor
 from talkshow_amd.pose_index import c_index_3d
 
 
@@ -87,7 +87,7 @@ class TrainWrapper(TrainWrapperBaseClass):
         """
         dev = self.generator._dev()
         mfcc = torch.as_tensor(mfcc, dtype=torch.float32, device=dev).contiguous()
-        ids = torch.as_tensor(ids, dtype=torch.int64, device=dev).reshape(-1).contiguous()
+        ids = _index_tensor(ids, self.num_classes, 'speaker id', dev)   # IndexError like nn.Embedding; host inputs are checked without a sync
         B, T, _ = mfcc.shape
         H = T // 2 // 2
         # nn.Embedding of a single label broadcasts over the batch in the reference (gated_pixelcnn_v2.py:65-66)
@@ -95,7 +95,6 @@ class TrainWrapper(TrainWrapperBaseClass):
             ids = ids.repeat(B)
         if ids.numel() != B:
             raise ValueError(f"ids must hold 1 or B={B} speaker indices, got {ids.numel()}")
-        _check_index_range(ids, self.num_classes, 'speaker id')   # IndexError like nn.Embedding; sync-free once seen
         codes = torch.zeros((B, H, 2), dtype=torch.int64, device=dev)
         poses = torch.empty((B, 4 * H, self.each_dim[1] + self.each_dim[2]), dtype=torch.float32, device=dev)
         if uniforms is not None:

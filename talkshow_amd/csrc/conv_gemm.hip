@@ -278,18 +278,12 @@ static int pick_tile(const ConvParams &p) {
     // inside the real layer sequence (304-335 us vs 298-310 us for 64x64), so the model does not pick it.
     struct Cand { int id, bm, bn; double eff; };
     static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 64, 0.92}, {3, 128, 64, 0.95}, {4, 64, 128, 0.95}};
-    static const int big = [] { const char *e = getenv("TS_CONV_BIG"); return e ? atoi(e) : 0; }();   // 8 / 9: try the 256-wide tiles
     int best = 2;
     double best_cost = 1e300;
     for (const Cand &c : cands) {
         const long tiles = (long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * p.ngroups;
         const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
         if (cost < best_cost) { best_cost = cost; best = c.id; }
-    }
-    if (big == 8 || big == 9) {   // experimental: only where at least ~4 waves of the big tile exist
-        const int bm = big == 8 ? 256 : 128, bn = big == 8 ? 128 : 256;
-        const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.ngroups;
-        if (tiles >= 1000 && p.N % bn == 0) return big;
     }
     return best;
 }
@@ -302,29 +296,22 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
     }
     if (tile == 0) tile = pick_tile(p);
     dim3 block(256);
-    // TS_CONV_PAD_LDS: extra dynamic LDS per workgroup (occupancy experiments: 16384 caps the 128x128 tile at one workgroup per
-    // CU, leaving room for a chain workgroup of another stream beside it)
-    static const int pad_lds = [] { const char *e = getenv("TS_CONV_PAD_LDS"); return e ? atoi(e) : 0; }();
     auto grid = [&](int bm, int bn) { return dim3((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, p.ngroups); };
     // zero buffer (ts::skinny_init, called by ts_ctx_create): 64 Ki floats; parked pointers walk at most Ktot floats of it
     if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000) return hipErrorInvalidValue;
     switch (tile) {
-        case 1: hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 64, 64>), grid(128, 128), block, pad_lds, stream, p); break;
-        case 2: hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32>), grid(64, 64), block, pad_lds, stream, p); break;
-        case 3: hipLaunchKernelGGL((conv_gemm_kernel<128, 64, 64, 32>), grid(128, 64), block, pad_lds, stream, p); break;
-        case 4: hipLaunchKernelGGL((conv_gemm_kernel<64, 128, 32, 64>), grid(64, 128), block, pad_lds, stream, p); break;
+        case 1: hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 64, 64>), grid(128, 128), block, 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32>), grid(64, 64), block, 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((conv_gemm_kernel<128, 64, 64, 32>), grid(128, 64), block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((conv_gemm_kernel<64, 128, 32, 64>), grid(64, 128), block, 0, stream, p); break;
         case 5:   // 64x64 with 64-deep chunks (all segment lengths must be multiples of 64)
-            hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32, 64>), grid(64, 64), block, pad_lds, stream, p);
+            hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32, 64>), grid(64, 64), block, 0, stream, p);
             break;
         // tall tiles, waves side by side along N (each 32 columns x the whole tile height): 160x128 turns the three big
         // layer shapes of the VQ stacks at batch 32 (M*N = 2 x 2400x1024 = 2 x 4800x512 = 2 x 9600x256) into exactly 240
         // tiles, one per CU in a single wave, with the L2->LDS traffic per MAC of the 128x128 tile
-        case 6: hipLaunchKernelGGL((conv_gemm_kernel<160, 128, 160, 32>), grid(160, 128), block, pad_lds, stream, p); break;
-        case 7: hipLaunchKernelGGL((conv_gemm_kernel<96, 128, 96, 32>), grid(96, 128), block, pad_lds, stream, p); break;
-        // 256-wide tiles, one workgroup (one wave per SIMD, up to 512 registers) per CU: 0.047 operand bytes per MAC instead
-        // of 0.0625 — the kernel is bound by what a CU can pull through its L1 (~10-11 B/clk), not by the matrix pipe
-        case 8: hipLaunchKernelGGL((conv_gemm_kernel<256, 128, 128, 64>), grid(256, 128), block, pad_lds, stream, p); break;
-        case 9: hipLaunchKernelGGL((conv_gemm_kernel<128, 256, 64, 128>), grid(128, 256), block, pad_lds, stream, p); break;
+        case 6: hipLaunchKernelGGL((conv_gemm_kernel<160, 128, 160, 32>), grid(160, 128), block, 0, stream, p); break;
+        case 7: hipLaunchKernelGGL((conv_gemm_kernel<96, 128, 96, 32>), grid(96, 128), block, 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

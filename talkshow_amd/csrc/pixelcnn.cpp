@@ -64,7 +64,6 @@ struct ts_pixelcnn {
     DevBuf w1m, b1m;                                         // head1': [HID][D or 2D], [HID]
     ConvLayer aud_h1;                                        // Wh1_1 applied to AEH for every row (l = 1 has AEH in place of XH_0)
     bool use_graph = true;
-    bool pair_vh = true;
     int defer_p = -1;     // the next-row projections P_l of the vertical stack ride with column 1's launches: -1 auto, 0 never, 1 always
     // tiled operand layouts (kernels.h, SkinnyParams::w_tiled): every weight matrix of the chain gets a tiled twin, and
     // the activation buffers that feed the next stage's GEMM (OV0, XV, HV, G, XH, Y) are written / read tiled
@@ -519,7 +518,7 @@ int run_row(ts_pixelcnn *p, const RunCfg &c, int r, bool need_h, hipStream_t s) 
     // tile shape — 16 more than CUs, and the 16 doubled-up CUs set the launch time (5.9 vs 3.6 us at 32 clips).  The P_l
     // projections are only read by the next row: there they ride with column 1's launches (96 -> 160 workgroups).
     std::vector<SkinnyParams> Pd;
-    const bool defer = need_h && p->pair_vh && (p->defer_p < 0 ? c.B <= 128 : p->defer_p > 0);
+    const bool defer = need_h && (p->defer_p < 0 ? c.B <= 128 : p->defer_p > 0);
     build_vertical(p, c, r, V, defer ? &Pd : nullptr);
     if (!need_h) {
         for (auto &sl : V) TS_TRY(launch_slot(p, c.w, sl, nullptr, s));
@@ -527,19 +526,14 @@ int run_row(ts_pixelcnn *p, const RunCfg &c, int r, bool need_h, hipStream_t s) 
     }
     build_horizontal(p, c, r, 0, H);
     size_t vi = 0;
-    if (p->pair_vh) {
-        // hg_0 needs V2H_0 (V1); S_k needs V2H_k (V_{k+1}): V0, V1, H0 + V2, H1 + V3, ...
-        for (; vi < 2 && vi < V.size(); ++vi) TS_TRY(launch_slot(p, c.w, V[vi], nullptr, s));
-        for (size_t k = 0; k < H.size(); ++k) {
-            const Slot *ride = nullptr;
-            if (vi < V.size() && V[vi].n + H[k].n <= SKINNY_MAX_PROBLEMS) ride = &V[vi++];
-            TS_TRY(launch_slot(p, c.w, H[k], ride, s));
-        }
-        for (; vi < V.size(); ++vi) TS_TRY(launch_slot(p, c.w, V[vi], nullptr, s));   // only if the stack outlasts the chain
-    } else {
-        for (auto &sl : V) TS_TRY(launch_slot(p, c.w, sl, nullptr, s));
-        for (auto &sl : H) TS_TRY(launch_slot(p, c.w, sl, nullptr, s));
+    // hg_0 needs V2H_0 (V1); S_k needs V2H_k (V_{k+1}): V0, V1, H0 + V2, H1 + V3, ...
+    for (; vi < 2 && vi < V.size(); ++vi) TS_TRY(launch_slot(p, c.w, V[vi], nullptr, s));
+    for (size_t k = 0; k < H.size(); ++k) {
+        const Slot *ride = nullptr;
+        if (vi < V.size() && V[vi].n + H[k].n <= SKINNY_MAX_PROBLEMS) ride = &V[vi++];
+        TS_TRY(launch_slot(p, c.w, H[k], ride, s));
     }
+    for (; vi < V.size(); ++vi) TS_TRY(launch_slot(p, c.w, V[vi], nullptr, s));   // only if the stack outlasts the chain
     TS_TRY(launch_sampler(p, c, r, 0, s));
     build_horizontal(p, c, r, 1, H);
     size_t pi = 0;
@@ -804,7 +798,6 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
     }
     if (const char *e = std::getenv("TS_NO_GRAPH")) p->use_graph = !(e[0] && e[0] != '0');
     if (const char *e = std::getenv("TS_PIX_DEFER_P")) p->defer_p = std::atoi(e);
-    if (const char *e = std::getenv("TS_NO_PAIR")) p->pair_vh = !(e[0] && e[0] != '0');
     *out = p.release();
     return 0;
 }

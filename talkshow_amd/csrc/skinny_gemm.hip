@@ -372,18 +372,11 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
     int dws[SKINNY_MAX_PROBLEMS];
 #pragma unroll
     for (int i = 0; i < SKINNY_MAX_PROBLEMS; ++i) dws[i] = (int)batch.d[i].w[lane];
-    // XCD-aware order (coalesced batches): the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each
-    // with a private L2.  Workgroup id b is given logical tile (b % 8) * (n / 8) + b / 8, so that one XCD owns a
-    // CONTIGUOUS eighth of the (problem, column tile) space: it pulls only its eighth of the stage's weights through the
-    // fabric and its row tiles re-read them from its own L2 (tiles are enumerated column-major inside a problem).
-    // start[6] & 2 — the balanced form: every PROBLEM's column tiles are dealt over the XCDs (column tile c belongs to XCD
-    // c % 8), so each XCD gets an eighth of every problem (problems differ in K) and still pulls only an eighth of the weights.
-    int bx = blockIdx.x;
-    const int xmode = batch.start[6];
-    if (xmode & 1) {
-        const int per = (int)gridDim.x >> 3;
-        if (bx < per * 8) bx = (bx & 7) * per + (bx >> 3);
-    }
+    // keep these six loads the FIRST thing the wave issues: left alone, hipcc sinks them behind the scalar loads of start[] and the
+    // problem search below (it even folds two of them into one load of a selected address), which puts a second round trip in
+    // front of the descriptor — 0.3 us per launch, 4 % of a 32-clip chain (the "code layout" swings of round 2 were this)
+    __builtin_amdgcn_sched_barrier(0);
+    const int bx = blockIdx.x;
     int z = 0, first = 0;
 #pragma unroll
     for (int i = 1; i < SKINNY_MAX_PROBLEMS; ++i) {
@@ -402,18 +395,8 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
     const int nmt = (M + ROWS - 1) / ROWS;      // row tiles; tiles of a problem are enumerated column-major
     // scalar integer division costs ~30 instructions on the way to the first operand load: the usual divisors (row tiles per
     // problem, gate tiles per group, class-row width) are powers of two.  Same-box A/B: 37.1 -> 36.4 ms per 256-clip pass.
-    // (The instruction stream ahead of the loads is worth ~0.1 us per 100 instructions here — and removing the dead `xmode & 1`
-    // branch below or fetching start[] with one scalar load made the launch 4 % SLOWER, twice: code layout, not logic.)
     auto sdiv = [](int x, int d) { return (d & (d - 1)) == 0 ? x >> __builtin_ctz(d) : x / d; };
-    int tile, mt;
-    if (xmode & 2) {   // host guarantees: every problem starts at a multiple of 8 and has a multiple of 8 column tiles
-        const int t = bx - first, sl = t >> 3, tl = sdiv(sl, nmt);
-        mt = sl - tl * nmt;
-        tile = tl * 8 + (t & 7);
-    } else {
-        tile = sdiv(bx - first, nmt);
-        mt = (bx - first) - tile * nmt;
-    }
+    const int tile = sdiv(bx - first, nmt), mt = (bx - first) - tile * nmt;
     if (TRACE) tr[1] = wall_clock64();
 
     const bool gate = flags & SDF_GATE;
@@ -791,10 +774,9 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
     }
     dim3 grid(gx, gy, n);
     // K is split over the waves of the workgroup; more waves = more loads in flight (lower latency for ONE chain) but a
-    // fatter workgroup.  TS_SKINNY_MAXW caps it (tuning).
-    static const int maxw = [] { const char *e = getenv("TS_SKINNY_MAXW"); return e ? atoi(e) : 16; }();
+    // fatter workgroup
     if (ncol == 16) {   // Q counts 8-k steps: K = 8 Q; the 16-column kernel keeps 8 accumulators -> at most 8 waves
-        const int W16 = (Q >= 32 && maxw >= 8) ? 8 : 4;
+        const int W16 = Q >= 32 ? 8 : 4;
         static const int variant = [] { const char *e = getenv("TS_SKINNY_V"); return e ? atoi(e) : 1; }();
         int dev = 0;
         if (variant != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_zero[dev]) {
@@ -813,15 +795,24 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
                 if (wide && wM >= 64) {
                     int total = 0, items[SKINNY_MAX_PROBLEMS];
                     for (int i = 0; i < 8; ++i) db.start[i] = 0x7fffffff;
-                    for (int i = 0; i < n; ++i) {
-                        // a workgroup works through `items` tiles: problems with a fraction of the launch's biggest K get
-                        // several, so that every workgroup carries about the same work (an epilogue-only tile counts as 4 q-steps)
-                        const int cost = Qp[i] > 4 ? Qp[i] : 4;
-                        items[i] = Qmax / cost < 1 ? 1 : (Qmax / cost > 4 ? 4 : Qmax / cost);
-                        const int tiles = (b.p[i].N / 64) * ((b.p[i].M + 63) / 64);
-                        db.start[i] = total;
-                        total += (tiles + items[i] - 1) / items[i];
-                    }
+                    // one tile per workgroup while the launch fits one workgroup per CU.  Beyond that, workgroups of equal work
+                    // (problems with a fraction of the launch's biggest K get several tiles; an epilogue-only tile counts as 4
+                    // q-steps), and as many such units per workgroup as it takes to stay within one round: a workgroup's next
+                    // tile is prefetched under the epilogue of the current one, a second ROUND of workgroups pays the start-up again
+                    auto count_wgs = [&](int mult) {
+                        int t = 0;
+                        for (int i = 0; i < n; ++i) {
+                            const int cost = Qp[i] > 4 ? Qp[i] : 4;
+                            const int eq = Qmax / cost < 1 ? 1 : (Qmax / cost > 4 ? 4 : Qmax / cost);
+                            items[i] = mult == 0 ? 1 : eq * mult;
+                            const int tiles = (b.p[i].N / 64) * ((b.p[i].M + 63) / 64);
+                            db.start[i] = t;
+                            t += (tiles + items[i] - 1) / items[i];
+                        }
+                        return t;
+                    };
+                    total = count_wgs(0);
+                    for (int mult = 1; total > 256 && mult <= 8; ++mult) total = count_wgs(mult);
                     if (total >= wide_min) {
                         for (int i = 0; i < n && wide; ++i) {
                             wide = skinny_pack_desc(b.p[i], W16, g_zero[dev], db.d[i]);
@@ -831,15 +822,13 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
                         for (int i = n; i < SKINNY_MAX_PROBLEMS; ++i) std::memset(&db.d[i], 0, sizeof(SkinnyDesc));
                         if (wide) {
                             db.start[6] = db.start[7] = 0;
-                            static const int wide_xcd = [] { const char *e = getenv("TS_SKINNY_WIDE_XCD"); return e ? atoi(e) : 0; }();
-                            db.start[0] = wide_xcd;   // launch flags (problem 0 always starts at workgroup 0)
+                            static const int wide_abl = [] { const char *e = getenv("TS_SKINNY_WIDE_ABLATE"); return e ? atoi(e) : 0; }();
+                            db.start[0] = g_trace_host ? wide_abl : 0;   // trace builds only: 2 = no loads, 4 = no MFMAs (problem 0 always starts at workgroup 0)
                             if (g_trace_host) {
                                 const uint64_t rec = (uint64_t)(uintptr_t)(g_trace_host + (size_t)(g_trace_seq++ % TRACE_LAUNCHES) * TRACE_WGS * TRACE_REC);
                                 db.start[6] = (int)(uint32_t)rec;
                                 db.start[7] = (int)(uint32_t)(rec >> 32);
                             }
-                            static const int twice = [] { const char *e = getenv("TS_SKINNY_WIDE_TWICE"); return e ? atoi(e) : 0; }();
-                            if (twice) (void)launch_skinny_wide(db, total, stream, false);   // experiment: the 2nd launch finds its operands in L2
                             return launch_skinny_wide(db, total, stream, g_trace_host != nullptr);
                         }
                     }
@@ -848,9 +837,8 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
             // Tile shape (rows x columns in blocks of 16).  One batch (M <= 32): 16-row tiles when the launch then still
             // fits one workgroup per CU (less to fetch per CU), else 32 x 16.  Coalesced batches (M >= 64): the biggest of
             // 64 x 32 / 32 x 32 / 32 x 16 that still spreads the launch over about all CUs (fewer operand bytes per output).
-            static const int half_max = [] { const char *e = getenv("TS_SKINNY_HALF_MAX"); return e ? atoi(e) : 256; }();
-            static const int fat_min = [] { const char *e = getenv("TS_SKINNY_FAT_MIN"); return e ? atoi(e) : 200; }();
-            static const int force_shape = [] { const char *e = getenv("TS_SKINNY_SHAPE"); return e ? atoi(e) : 0; }();   // 11, 21, 22, 42
+            constexpr int half_max = 256, fat_min = 200;
+            static const int force_shape = [] { const char *e = getenv("TS_SKINNY_SHAPE"); return e ? atoi(e) : 0; }();   // 11, 21, 22, 42 (tests)
             int maxM = 0, maxcnt = 0;
             bool even = true;
             for (int i = 0; i < n; ++i) {
@@ -865,32 +853,22 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
                 return t;
             };
             int RB = 2, CB = 1;
-            bool quad = even;
-            for (int i = 0; i < n; ++i)
-                if (b.p[i].grid_x % 4) quad = false;
             if (force_shape) {
                 RB = force_shape / 10;
                 CB = force_shape % 10;
-                if (CB == 4 && (!quad || maxcnt > 4)) CB = 2;
+                if (CB > 2) CB = 2;
+                if (RB > 4) RB = 4;
                 if (CB == 2 && (!even || maxcnt > 4)) CB = 1;
                 if (CB == 1 && RB > 2) RB = 2;
             } else if (maxM <= 32) {
                 if (count(16, 1) <= half_max) RB = 1;
             } else if (even && maxcnt <= 4) {
-                static const int quad_max = [] { const char *e = getenv("TS_SKINNY_QUAD_MAX"); return e ? atoi(e) : 0; }();
-                if (quad && quad_max > 0 && count(64, 4) >= fat_min && count(64, 4) <= quad_max) { RB = 4; CB = 4; }
-                else if (count(64, 2) >= fat_min) { RB = 4; CB = 2; }
+                if (count(64, 2) >= fat_min) { RB = 4; CB = 2; }
                 else if (count(32, 2) >= fat_min) { RB = 2; CB = 2; }
             }
             const int rows = RB * 16;
             int total = 0;
             for (int i = 0; i < 8; ++i) db.start[i] = 0x7fffffff;
-            static const int xcd_min = [] { const char *e = getenv("TS_SKINNY_XCD_MIN_M"); return e ? atoi(e) : (1 << 30); }();
-            static const int xcd_mode = [] { const char *e = getenv("TS_SKINNY_XCD_MODE"); return e ? atoi(e) : 2; }();
-            bool by8 = true;
-            for (int i = 0; i < n; ++i)
-                if ((b.p[i].grid_x / CB) % 8) by8 = false;
-            db.start[6] = maxM >= xcd_min ? (xcd_mode == 2 ? (by8 ? 2 : 0) : 1) : 0;
             for (int i = 0; i < n && fast; ++i) {
                 fast = skinny_pack_desc(b.p[i], W16, g_zero[dev], db.d[i]);
                 db.start[i] = total;
@@ -902,26 +880,20 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
                 static const int trace = [] { const char *e = getenv("TS_SKINNY_TRACE"); return e ? atoi(e) : 0; }();
                 if (trace) db.start[7] = (int)(g_trace_seq++);
                 const int shape = RB * 10 + CB;
-                // TS_SKINNY_PAD_LDS: extra dynamic LDS per workgroup (occupancy experiments: e.g. 24576 caps the 64 x 32 tile
-                // at one workgroup per CU so that a conv_gemm workgroup of another stream can sit beside it)
-                static const int pad_lds = [] { const char *e = getenv("TS_SKINNY_PAD_LDS"); return e ? atoi(e) : 0; }();
-                const int dyn_lds = (RB * CB == 8) ? pad_lds : 0;
 #define TS_SK_LAUNCH(Wv, R, C)                                                                                         \
     do {                                                                                                               \
-        if (trace) hipLaunchKernelGGL((skinny16_fast_kernel<Wv, R, C, true>), grid, dim3(Wv * 64), dyn_lds, stream, db); \
-        else hipLaunchKernelGGL((skinny16_fast_kernel<Wv, R, C, false>), grid, dim3(Wv * 64), dyn_lds, stream, db);     \
+        if (trace) hipLaunchKernelGGL((skinny16_fast_kernel<Wv, R, C, true>), grid, dim3(Wv * 64), 0, stream, db); \
+        else hipLaunchKernelGGL((skinny16_fast_kernel<Wv, R, C, false>), grid, dim3(Wv * 64), 0, stream, db);     \
     } while (0)
                 if (W16 == 8) {
                     if (shape == 11) TS_SK_LAUNCH(8, 1, 1);
                     else if (shape == 21) TS_SK_LAUNCH(8, 2, 1);
                     else if (shape == 22) TS_SK_LAUNCH(8, 2, 2);
-                    else if (shape == 44) TS_SK_LAUNCH(8, 4, 4);
                     else TS_SK_LAUNCH(8, 4, 2);
                 } else {
                     if (shape == 11) TS_SK_LAUNCH(4, 1, 1);
                     else if (shape == 21) TS_SK_LAUNCH(4, 2, 1);
                     else if (shape == 22) TS_SK_LAUNCH(4, 2, 2);
-                    else if (shape == 44) TS_SK_LAUNCH(4, 4, 4);
                     else TS_SK_LAUNCH(4, 4, 2);
                 }
 #undef TS_SK_LAUNCH
@@ -938,8 +910,7 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
         else hipLaunchKernelGGL(skinny16_kernel<4>, grid, dim3(256), 0, stream, b);
         return hipGetLastError();
     }
-    int W = Q >= 64 ? 16 : (Q >= 32 ? 8 : 4);
-    if (W > maxw) W = maxw;
+    const int W = Q >= 64 ? 16 : (Q >= 32 ? 8 : 4);
     if (W >= 16) hipLaunchKernelGGL(skinny_gemm_kernel<16>, grid, dim3(1024), 0, stream, b);
     else if (W >= 8) hipLaunchKernelGGL(skinny_gemm_kernel<8>, grid, dim3(512), 0, stream, b);
     else hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, dim3(256), 0, stream, b);

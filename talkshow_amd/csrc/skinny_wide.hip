@@ -19,6 +19,8 @@
 //   * problems with half the K of the launch's biggest get two tiles per workgroup (SD_ITEMS), so that every workgroup
 //     of a launch carries about the same work and a launch is about one workgroup per CU.
 // Reference arithmetic: nets/spg/gated_pixelcnn_v2.py:61-87,120-124 (one stage of GatedMaskedConv2d / the logits head).
+#include <cstdlib>
+
 #include "skinny_desc.h"
 
 namespace ts {
@@ -56,15 +58,11 @@ __global__ __launch_bounds__(512, 2) void skinny16_wide_kernel(const SkinnyDescB
     int dws[SKINNY_MAX_PROBLEMS];
 #pragma unroll
     for (int i = 0; i < SKINNY_MAX_PROBLEMS; ++i) dws[i] = (int)batch.d[i].w[lane];
-    // XCD-aware order (start[0] & 1): the hardware deals workgroup ids round-robin over the 8 XCDs, each with a private L2.
-    // Logical work item (xcd, slot) -> a CONTIGUOUS eighth of the launch's (problem, column tile, row tile) list, so that the
-    // row tiles sharing a weight column block pull it through ONE L2 (every workgroup of a launch carries the same work, so
-    // contiguous eighths are balanced)
-    int bx = blockIdx.x;
-    if (batch.start[0] & 1) {
-        const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bx & 7;
-        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);
-    }
+    // keep these six loads the FIRST thing the wave issues: left alone, hipcc sinks them behind the scalar loads of start[] and the
+    // problem search below (it even folds two of them into one load of a selected address), which puts a second round trip in
+    // front of the descriptor — 0.3 us per launch, 4 % of a 32-clip chain (the "code layout" swings of round 2 were this)
+    __builtin_amdgcn_sched_barrier(0);
+    const int bx = blockIdx.x;
     int z = 0, first = 0;
 #pragma unroll
     for (int i = 1; i < SKINNY_MAX_PROBLEMS; ++i) {
@@ -86,15 +84,10 @@ __global__ __launch_bounds__(512, 2) void skinny16_wide_kernel(const SkinnyDescB
     const bool gate = flags & SDF_GATE;
     const int wr = wave >> 1, wc = wave & 1;
 
-    for (int it = 0; it < items; ++it) {
-        const int idx = (bx - first) * items + it;
-        if (idx >= ntile) break;
-        const int tile = sdiv(idx, nmt), mt = idx - tile * nmt;   // tiles of a problem are enumerated column-major
-        if (it) __builtin_amdgcn_s_barrier();                     // the ring is reused: every wave is done reading the last tile's stages
-
-        // ---- loader role: waves 0..3 stream activation row block `wave`, waves 4..7 weight column block `wave - 4` ----
-        gcf *sp0, *sp1 = nullptr, *sp2 = nullptr;
-        int st0, st1 = 0, st2 = 0, l0, l1 = 0, nsegw = 1;
+    // ---- loader role: waves 0..3 stream activation row block `wave`, waves 4..7 weight column block `wave - 4` ----
+    gcf *sp0 = nullptr, *sp1 = nullptr, *sp2 = nullptr;
+    int st0 = 0, st1 = 0, st2 = 0, l0 = 0, l1 = 0, nsegw = 1;
+    auto setup_loader = [&](int tile, int mt) {
         if (wave >= 4) {
             sp0 = P(SD_W) + ((((long)(tile * 4 + wave - 4) * Q) << 6) + lane) * 4;
             st0 = 256;
@@ -130,6 +123,13 @@ __global__ __launch_bounds__(512, 2) void skinny16_wide_kernel(const SkinnyDescB
             }
             if (nsegw > 2) sp2 = seg_ptr(SD_SEG + 2 * SD_SEG_WORDS, st2);
         }
+    };
+    bool prefetched = false;   // the tile's first two stages were issued behind the previous tile's last MFMAs
+
+    for (int it = 0; it < items; ++it) {
+        const int idx = (bx - first) * items + it;
+        if (idx >= ntile) break;
+        const int tile = sdiv(idx, nmt), mt = idx - tile * nmt;   // tiles of a problem are enumerated column-major
         const bool abl_noload = TRACE && (batch.start[0] & 2), abl_nomfma = TRACE && (batch.start[0] & 4);
         auto issue = [&](int t) {   // stage t = q-steps 4 t .. 4 t + 3, inside one segment (host-checked)
             if (abl_noload) return;
@@ -149,18 +149,23 @@ __global__ __launch_bounds__(512, 2) void skinny16_wide_kernel(const SkinnyDescB
             for (int qq = 0; qq < WIDE_QS; ++qq) glds16(p + (long)qq * step, dst + qq * 8 * 64);
         };
 
-        // ---- the first stages go out before anything else is computed: they are what the first MFMA waits for ----
-        // (stages 2, 3 follow behind the first barrier: sixteen 1 KB loads per wave up front take 1.3 us to issue — the memory
-        // pipeline pushes back — and stage 0 queues behind them; loads stream twice as fast as the MFMAs consume them)
-        const int npro = T < 2 ? T : 2;
-        if (it == 0) TS_STAMP(1);
-        if (npro > 0) issue(0);
-        asm volatile("" ::: "memory");
+        // ---- the first two stages go out before anything else is computed: they are what the first MFMA waits for.
+        // (Later stages follow behind the first barrier: sixteen 1 KB loads per wave up front take 1.3 us to issue — the memory
+        // pipeline pushes back — and stage 0 queues behind them; loads stream twice as fast as the MFMAs consume them.)
+        if (!prefetched) {
+            setup_loader(tile, mt);
+            if (it == 0) TS_STAMP(1);
+            if (T > 0) issue(0);
+            if (T > 1) issue(1);
+            if (it == 0) TS_STAMP(14);
+        }
+        prefetched = false;
 
         // ---- epilogue operands of this wave's two 16 x 16 blocks: activation row m, 4 consecutive channels from n0.
-        // Issued between stage 0 and stage 1: the first counted wait (all but the 4 youngest) covers them too.  The
-        // counted waits below count LDS-DMA loads only; a plain load the compiler moves to a later position can make them
-        // stricter than needed, never weaker (a wait for "at most N outstanding" with N = the younger LDS-DMA loads).
+        // Fetched behind the first barrier, ahead of the refill of stages 2..4 (a gate's terms were written by the previous
+        // launch: ahead of the first wait they put a cold round trip in front of the first MFMA).  The counted waits count
+        // LDS-DMA loads only; a plain load sitting at a later position in the queue can make them stricter than needed,
+        // never weaker (a wait for "at most N outstanding" with N = the younger LDS-DMA loads).
         const int mrow = mt * 64 + wr * 16 + li;
         const bool m_ok = mrow < M;
         const int mcl = m_ok ? mrow : 0;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void skinny16_wide_kernel(const SkinnyDescB
         }
         const int add1_tw = I(SD_ADD1_TW), out_tw = I(SD_OUT_TW), pre_tw = I(SD_PRE_TW);
         f32x4 t0[2], t1[2], t2[2], t3[2], ecls[2];
-        {
+        auto epi_load = [&]() {
             const int cls_ld = I(SD_CLS_LD);
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
@@ -192,10 +197,7 @@ __global__ __launch_bounds__(512, 2) void skinny16_wide_kernel(const SkinnyDescB
                 const int ccol = (cls_ld & (cls_ld - 1)) == 0 ? (n0[cb] & (cls_ld - 1)) : n0[cb] % cls_ld;
                 ecls[cb] = *reinterpret_cast<gcf4 *>(P(SD_CLS) + (long)mcl * cls_ld + ccol);
             }
-        }
-        asm volatile("" ::: "memory");
-        for (int t = 1; t < npro; ++t) issue(t);
-        if (it == 0) TS_STAMP(14);
+        };
 
         // ---- main loop.  A stage's fragments sit in registers (two sets, alternating); the barrier that opens stage t+1
         // falls between the MFMAs of q-steps 1 and 2 of stage t.  The two waves of a SIMD (w, w + 4) take turns behind it: waves
@@ -251,37 +253,53 @@ __global__ __launch_bounds__(512, 2) void skinny16_wide_kernel(const SkinnyDescB
                 const bool more = t + 1 < TS;
                 auto refill = [&]() {
                     if (t == 0) {
+                        epi_load();
+                        asm volatile("" ::: "memory");
                         if (2 < TS) issue(2);
                         if (3 < TS) issue(3);
                     }
                     if (t + WIDE_NS < TS) issue(t + WIDE_NS);   // into the slot of stage t
                 };
-                mfma_q(t, 0);
-                mfma_q(t, 1);
-                if (CN == 2) fold();
-                if (more) {
+                auto open_next = [&]() {   // the barrier that opens stage t+1
+                    if (!more) return;
                     const int youngest = t == 0 ? 1 : (t + WIDE_NS - 1 < TS - 1 ? t + WIDE_NS - 1 : TS - 1);
                     wait_stage(youngest - (t + 1));   // ... and every LDS read of stage t is done (lgkmcnt)
                     __builtin_amdgcn_s_barrier();     // everybody's loads of stage t+1 have landed; everybody holds stage t in registers
                     asm volatile("" ::: "memory");
                     if (it == 0 && t + 1 < 8) TS_STAMP(6 + t + 1);
-                }
-                // sched_barrier: hipcc otherwise sinks the LDS reads to just ahead of their MFMAs (lgkmcnt(0) stalls with no cover)
-                __builtin_amdgcn_sched_barrier(0);
+                };
+                // The matrix pipe goes to the OLDER wave whenever both have an MFMA ready (tools/mfma_rate.cpp), and an LDS-DMA
+                // load takes ~190 cycles to issue against the CU's fetch rate: a wave's refill + LDS reads (~900 cycles) need
+                // the partner's MFMAs as cover.  The younger wave therefore crosses the barrier one q-step EARLY, keeping 24
+                // MFMAs for the time its partner loads; the older wave then computes 32 in a row while the younger one loads.
+                // (sched_barrier: hipcc otherwise sinks the LDS reads to just ahead of their MFMAs — lgkmcnt(0) stalls with no cover)
                 if (wave < 4) {
+                    mfma_q(t, 0);
+                    mfma_q(t, 1);
+                    if (CN == 2) fold();
+                    open_next();
+                    __builtin_amdgcn_sched_barrier(0);
                     refill();
                     if (more) read_stage(t + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_q(t, 2);
-                mfma_q(t, 3);
-                fold();
-                __builtin_amdgcn_sched_barrier(0);
-                if (wave >= 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_q(t, 2);
+                    mfma_q(t, 3);
+                    fold();
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    mfma_q(t, 0);
+                    open_next();
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_q(t, 1);
+                    if (CN == 2) fold();
+                    mfma_q(t, 2);
+                    mfma_q(t, 3);
+                    fold();
+                    __builtin_amdgcn_sched_barrier(0);
                     if (more) read_stage(t + 1);
                     refill();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         };
         auto run_rolled = [&]() {   // stage t is consumed while stages t+1 .. t+3 are in flight; one barrier per stage
@@ -309,7 +327,21 @@ __global__ __launch_bounds__(512, 2) void skinny16_wide_kernel(const SkinnyDescB
         };
         if (T == 8 && cnt == 4) run(IC<8>{}, IC<4>{});
         else if (T == 4 && cnt == 2) run(IC<4>{}, IC<2>{});
-        else if (T > 0) run_rolled();
+        else {
+            epi_load();
+            if (T > 0) run_rolled();
+        }
+        // the next tile of this workgroup: its first stages go out now and land under this tile's epilogue
+        if (it + 1 < items && idx + 1 < ntile) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // the ring is reused: every wave is done reading this tile's stages
+            asm volatile("" ::: "memory");
+            const int tile2 = sdiv(idx + 1, nmt), mt2 = idx + 1 - tile2 * nmt;
+            setup_loader(tile2, mt2);
+            if (T > 0) issue(0);
+            if (T > 1) issue(1);
+            prefetched = true;
+        }
 
         if (TRACE && it == 0) {
             TS_STAMP(2);

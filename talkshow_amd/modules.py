@@ -112,20 +112,37 @@ class NativeModule:
         return torch.device("cuda", self._require_hip())
 
 
-_range_ok = set()
+_range_seen = {}   # (id(owning tensor), view geometry, n) -> (weakref to the owner, _version): caller-owned device tensors already checked
 
 
-def _check_index_range(t, n, what):
-    """IndexError for indices outside [0, n) like nn.Embedding; the device->host sync is paid once per tensor version."""
-    key = (t.data_ptr(), t.numel(), t._version, n)
-    if key in _range_ok:
-        return
-    lo, hi = int(t.min()), int(t.max())
+def _check_index_range(x, n, what):
+    """IndexError for indices outside [0, n) like nn.Embedding.  Host-origin indices (ints, lists, numpy, CPU tensors) are
+    checked on the host before upload: no device sync.  A device tensor costs one device->host sync the first time this
+    tensor OBJECT is seen at this version; the cache holds a weak reference to the object (never its address: tensors built
+    inside a call get recycled addresses with _version 0, and a stale hit would skip the check)."""
+    import weakref
+    if isinstance(x, torch.Tensor) and x.is_cuda:
+        owner = x._base if x._base is not None else x       # a view (ids[:n]) is a new object per call: key on the tensor it views
+        key = (id(owner), x.storage_offset(), tuple(x.shape), tuple(x.stride()), n)
+        ent = _range_seen.get(key)
+        if ent is not None and ent[0]() is owner and ent[1] == x._version:
+            return
+        lo, hi = (int(x.min()), int(x.max())) if x.numel() else (0, 0)
+        if lo >= 0 and hi < n:
+            if len(_range_seen) > 256:
+                _range_seen.clear()
+            _range_seen[key] = (weakref.ref(owner), x._version)
+    else:
+        a = x.detach().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+        lo, hi = (int(a.min()), int(a.max())) if a.size else (0, 0)
     if lo < 0 or hi >= n:
         raise IndexError(f"{what} out of range: [{lo}, {hi}] not within [0, {n})")
-    if len(_range_ok) > 256:
-        _range_ok.clear()
-    _range_ok.add(key)
+
+
+def _index_tensor(x, n, what, device):
+    """x (int / list / numpy / tensor anywhere) -> flat contiguous int64 tensor on `device`, range-checked (see above)."""
+    _check_index_range(x, n, what)
+    return torch.as_tensor(x, dtype=torch.int64, device=device).reshape(-1).contiguous()
 
 
 def _dev_f32(x, device):
@@ -308,12 +325,11 @@ class GatedPixelCNN(NativeModule):
         dev = self._dev()
         aud_rows = _dev_f32(aud_rows, dev)
         B, H, _ = aud_rows.shape
-        label = torch.as_tensor(label, dtype=torch.int64, device=dev).reshape(-1).contiguous()
+        label = _index_tensor(label, self.n_classes, "class label", dev)
         if label.numel() == 1 and B > 1:
             label = label.repeat(B)
         if label.numel() != B:
             raise ValueError(f"label must hold 1 or B={B} class indices, got {label.numel()}")
-        _check_index_range(label, self.n_classes, "class label")
         if mode == _lib.TS_TEACHER_FORCED:
             codes = torch.as_tensor(codes, dtype=torch.int64, device=dev).contiguous()
         else:
@@ -368,12 +384,11 @@ class PixelCNNStream:
 
     def __init__(self, net, label, batch_size, max_chunk_rows):
         dev = net._dev()
-        label = torch.as_tensor(label, dtype=torch.int64, device=dev).reshape(-1).contiguous()
+        label = _index_tensor(label, net.n_classes, "class label", dev)
         if label.numel() == 1 and batch_size > 1:
             label = label.repeat(batch_size)
         if label.numel() != batch_size:
             raise ValueError(f"label must hold 1 or B={batch_size} class indices, got {label.numel()}")
-        _check_index_range(label, net.n_classes, "class label")
         self.net, self.B, self.max_rows = net, int(batch_size), int(max_chunk_rows)
         h = C.c_void_p()
         with torch.cuda.device(dev):

@@ -83,7 +83,7 @@ def test_conv_tile_shapes_agree(hip):
     ref = np.where(ref >= 0, ref, 0.2 * ref).astype(np.float32)
     xd, wd, bd = dev(x), dev(w), dev(b)
     outs = {}
-    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 0):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 0):
         out = torch.full((B, L, Cout), float("nan"), dtype=torch.float32, device="cuda")
         _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, tile, 1,
                                           _lib.dptr(out), None, None))
@@ -459,10 +459,11 @@ def test_full_size_properties(hip, tmp_path):
 
 
 def test_golden_clips_inside_baseline_batches(hip, golden, tmp_path):
-    """The two reference-golden clips (body_e2e_full, B=2) embedded at arbitrary slots of a BASELINE batch of 32 and of a
-    coalesced chain of 128 clips (4 batches in one launch sequence, 64 x 32 tiles): their codes must equal the golden
-    bit for bit and their poses stay within 1e-4 — the B=32 / B=128 results are pinned to the reference directly, not
-    only through self-consistency."""
+    """The two reference-golden clips (body_e2e_full, B=2) embedded at arbitrary slots of a BASELINE batch of 32, of a
+    coalesced chain of 128 clips (4 batches in one launch sequence, 64 x 32 split-K tiles), of the bench's 256-clip pass (the
+    64 x 64 full-K wide kernel, csrc/skinny_wide.hip) and of a 320-clip pass (ragged row tiles, several tiles per
+    workgroup): their codes must equal the golden bit for bit and their poses stay within 1e-4 — every operating point is
+    pinned to the reference directly, not only through self-consistency."""
     from nets.init_model import init_model
     from talkshow_amd import _lib
     g = golden("body_e2e_full")
@@ -470,7 +471,7 @@ def test_golden_clips_inside_baseline_batches(hip, golden, tmp_path):
     w = init_model("s2g_body_pixel", args, _config(tmp_path))
     w.load_state_dict({"generator": synth.to_torch(synth.pixelcnn_state_dict(seed=7)),
                        "audioencoder": synth.to_torch(synth.audioencoder_state_dict(seed=7))})
-    for B, slots in ((32, (3, 29)), (128, (70, 127))):
+    for B, slots in ((32, (3, 29)), (128, (70, 127)), (256, (64, 255)), (320, (77, 319))):
         mf, ids = synth.mfcc_features(90 + B, B, 300), synth.speaker_ids(B)
         for k, s_ in enumerate(slots):
             mf[s_], ids[s_] = g["mfcc"][k], g["ids"][k]
@@ -479,7 +480,7 @@ def test_golden_clips_inside_baseline_batches(hip, golden, tmp_path):
         for k, s_ in enumerate(slots):
             np.testing.assert_array_equal(codes[s_], g["codes"][k])
             np.testing.assert_allclose(poses[s_], g["poses"][k], atol=1e-4, rtol=0)
-        if B == 128:     # coalescing is invisible: each 32-clip batch alone gives the same bits
+        if B >= 128:     # coalescing is invisible: each 32-clip batch alone gives the same bits
             c32, p32 = w.generate_batch(mf[64:96], ids[64:96], mode=_lib.TS_SAMPLE_GREEDY)
             np.testing.assert_array_equal(c32.cpu().numpy(), codes[64:96])
             np.testing.assert_array_equal(p32.cpu().numpy(), poses[64:96])
@@ -669,17 +670,19 @@ def test_device_mfcc_vs_host_restatement(hip, tmp_path):
 
 
 @pytest.mark.parametrize("env", [{"TS_SKINNY_V": "0"}, {"TS_NO_GRAPH": "1"}, {"TS_SKINNY_NT": "32"},
-                                 {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"}, {"TS_SKINNY_SHAPE": "44"},
+                                 {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"},
                                  {"TS_SKINNY_TILED": "0", "TS_WITH_CLIPS": "1"}, {"TS_PIX_DEFER_P": "0", "TS_WITH_CLIPS": "1"},
-                                 {"TS_PIX_DEFER_P": "1", "TS_WITH_CLIPS": "1"}, {"TS_SKINNY_XCD_MIN_M": "0", "TS_WITH_CLIPS": "1"}],
+                                 {"TS_PIX_DEFER_P": "1", "TS_WITH_CLIPS": "1"}, {"TS_SKINNY_WIDE_MIN": "0", "TS_WITH_CLIPS": "1"},
+                                 {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}],
                          ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
-                              "tile_64x64", "row_major_operands", "projections_in_column0", "projections_in_column1",
-                              "xcd_tile_order"])
+                              "row_major_operands", "projections_in_column0", "projections_in_column1",
+                              "split_k_kernels_only", "wide_kernel_everywhere"])
 def test_alternate_kernel_paths(hip, env):
     """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
-    launches, the 32-column kernel), row-major instead of tiled operands, two placements of the next-row projections and an
-    XCD-aware tile order.  The knobs are read once per process, so the golden-vector tests are re-run in a child
-    process with each fallback forced: all paths must stay bit-exact on the codes."""
+    launches, the 32-column kernel), row-major instead of tiled operands, two placements of the next-row projections, and
+    the 64 x 64 wide kernel that coalesced passes use for launches of >= 160 workgroups (forced off / forced onto every
+    launch of >= 64 clips here, small head / column-1 launches included).  The knobs are read once per process, so the
+    golden-vector tests are re-run in a child process with each path forced: all must stay bit-exact on the codes."""
     import subprocess
     import sys
     child_env = dict(os.environ, **env)

@@ -192,3 +192,20 @@ def test_bench_pass_plan():
         eng.G = G
         assert eng.plan(steps) == want and sum(eng.plan(steps)) == steps
     assert bench.FRAMES_PER_CLIP == 300
+
+
+def test_index_range_check_has_no_stale_hits():
+    """the check used to cache on (data_ptr, numel, _version) — tensors built inside a call reuse addresses with
+    _version 0, so an out-of-range label could hit a stale entry.  Host-origin indices are now checked on the host every
+    time; the device-tensor cache holds a weak reference to the tensor object."""
+    from talkshow_amd.modules import _check_index_range
+    for _ in range(300):
+        _check_index_range(torch.tensor([3]).repeat(32), 4, "label")          # same allocation pattern, in range
+        with pytest.raises(IndexError):
+            _check_index_range(torch.tensor([4]).repeat(32), 4, "label")      # ... and out of range: never accepted
+    _check_index_range([0, 1, 2, 3], 4, "label")
+    _check_index_range(np.array([], dtype=np.int64), 4, "label")
+    _check_index_range(2, 4, "label")
+    for bad in ([0, -1], np.array([5]), 7, torch.tensor([[1, 9]])):
+        with pytest.raises(IndexError):
+            _check_index_range(bad, 4, "label")

@@ -84,3 +84,22 @@ for (g, wd), idx in sorted(kinds.items()):
         clk.append(np.median(R[i][5][full] / np.maximum(tf[:, 4] - tf[:, 0], 0.01)) / 1e3)
     ph = np.median(np.array(ph), axis=0)
     print(line + f" {np.median(sp):5.2f}  {dur:6.2f}   {per:6.2f}  | " + " ".join(f"{v:5.2f}" for v in ph) + f" | {np.median(life):5.2f} / {np.median(lifemax):5.2f} | shader clock {np.median(clk):.2f} GHz")
+
+# who are the stragglers?  workgroup life by problem index and by XCD (workgroup id % 8) for the most common wide launch kind
+if os.environ.get("TS_TRACE_DETAIL"):
+    common = max((k for k in kinds if k[1]), key=lambda k: len(kinds[k]))
+    lifez, lifex, st0 = {}, {}, {}
+    for i in kinds[common]:
+        a, b = launches[i]
+        x = r[a:b]
+        t = x[:, :16].astype(np.int64) * 0.01
+        zz = ((x[:, 5] >> np.uint64(48)) & np.uint64(0x3fff)).astype(np.int64)
+        # records are sorted by entry time, not by workgroup id: recover the id from the record's position in the launch block is not possible here,
+        # so the XCD view uses the entry order (dispatch order == id order within a launch)
+        order_in = np.argsort(np.argsort(t[:, 0], kind="stable"), kind="stable")
+        for k in range(len(x)):
+            lifez.setdefault(int(zz[k]), []).append(t[k, 4] - t[k, 0])
+            lifex.setdefault(int(order_in[k]) % 8, []).append(t[k, 4] - t[k, 0])
+            st0.setdefault(int(zz[k]), []).append(t[k, 6] - t[k, 0])
+    print(f"launch kind {common}: workgroup life by problem: " + "  ".join(f"z{z}: med {np.median(v):.2f} p95 {np.percentile(v, 95):.2f} max {np.max(v):.2f} (first data {np.median(st0[z]):.2f})" for z, v in sorted(lifez.items())))
+    print("   by dispatch slot % 8: " + "  ".join(f"{k}: {np.median(v):.2f}/{np.percentile(v, 95):.2f}" for k, v in sorted(lifex.items())))
