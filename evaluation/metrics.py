@@ -14,9 +14,11 @@ def data_driven_baselines(gt_kps):
 
 
 def LVD(gt_kps, pr_kps, symmetrical=False, weight=False):
-    if symmetrical or weight:
-        raise NotImplementedError("only the symmetrical=False, weight=False form is used (scripts/test_body.py:101)")
-    return E.lvd(gt_kps, pr_kps)
+    '''-> 0-d tensor like the reference (`metrics.py:27-94`).  weight=True is not offered: the reference draws its frame weights
+    with `.normal_()` on the velocity sums — fresh random numbers on every call, not a function of the inputs (`metrics.py:67-68`)'''
+    if weight:
+        raise NotImplementedError("weight=True draws random frame weights in the reference (metrics.py:67-68): no defined value")
+    return E.lvd(gt_kps, pr_kps, symmetrical=symmetrical)
 
 
 def diversity(kps):

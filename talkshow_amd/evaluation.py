@@ -84,9 +84,11 @@ def l1_mean_per_row(a, b, rows=None):
     a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
     n = a.shape[0] if rows is None else rows
     a, b = a[:n].contiguous(), b[:n].contiguous()
+    if a.shape[0] < n or b.shape[0] < n or a.shape[1] != b.shape[1]:
+        raise IndexError(f"feat_dist needs {n} rows of equal width in both arrays, got {tuple(a.shape)} and {tuple(b.shape)}")
     out = torch.empty(1, dtype=torch.float64, device=a.device)
     _lib.check(_lib.load().ts_eval_l1_total(_ctx(a), _lib.dptr(a), _lib.dptr(b), a.numel(), _lib.dptr(out), _lib.stream_ptr()))
-    return float(out.item()) / n
+    return np.float64(out.item() / n)            # numpy scalar like the reference's np.mean: callers do feat_dist.item()
 
 
 def body_loss(gt, prs, lvd_joints=22):
@@ -109,9 +111,36 @@ def body_loss(gt, prs, lvd_joints=22):
     return {'LVD': lvd / (B * (Tl - 1)), 'error': err / (B * T), 'diverse': var / T}
 
 
-def lvd(gt_kps, pr_kps):
-    """`evaluation.metrics.LVD(gt, pr)` for the non-symmetrical, unweighted case (`metrics.py:79-94`): gt (T,J,3),
-    pr (T,J,3) or (B,T,J,3)."""
+# SMPL-X body joints 0..21: the six on the spine (pelvis, spine1..3, neck, head = 0, 3, 6, 9, 12, 15) have no mirror image, the
+# others come as left / right pairs (1, 2), (4, 5), (7, 8), (10, 11), (13, 14), (16, 17), (18, 19), (20, 21)
+# (`data_utils/lower_body.py:136-141`: `rearrange` is the identity on these 22, `symmetry` flags the paired ones)
+_CENTRAL = [0, 3, 6, 9, 12, 15]
+_LEFT = [1, 4, 7, 10, 13, 16, 18, 20]
+_RIGHT = [2, 5, 8, 11, 14, 17, 19, 21]
+
+
+def lvd_symmetric(gt, pr):
+    """The symmetrical=True branch of `Batch_LVD` (`metrics.py:36-65`) on tensors of any device: gt (T,22,3), pr (B,T,22,3), equal T."""
+    if gt.shape[1] != 22 or pr.shape[2] != 22:
+        raise ValueError("symmetrical LVD is defined on the 22 SMPL-X body joints")
+    gv = (gt[1:] - gt[:-1]).norm(p=2, dim=-1)                       # (T-1, 22)
+    pv = (pr[:, 1:] - pr[:, :-1]).norm(p=2, dim=-1)                 # (B, T-1, 22)
+    g_side = (gv[:, _LEFT].sum(-1) > gv[:, _RIGHT].sum(-1)).to(gv.dtype)[:, None]
+    g_vel = torch.cat([gv[:, _CENTRAL], gv[:, _LEFT] * g_side + gv[:, _RIGHT] * (1 - g_side)], dim=1)
+    p_side = (pv[..., _LEFT].sum(-1) > pv[..., _RIGHT].sum(-1)).to(torch.int64)[..., None]
+    p_vel = torch.cat([pv[..., _CENTRAL], pv[..., _LEFT] * p_side + pv[..., _RIGHT] * (~p_side)], dim=2)   # ~ on an integer mask, as written
+    return ((p_vel - g_vel).abs().sum(-1) / g_vel.shape[0]).sum(-1).mean().to(torch.float32)
+
+
+def lvd(gt_kps, pr_kps, symmetrical=False):
+    """`evaluation.metrics.LVD(gt, pr, symmetrical, weight=False)` (`metrics.py:27-94`): gt (T,J,3), pr (T,J,3) or (B,T,J,3)
+    -> 0-d float32 tensor on pr's device (the reference returns a tensor: its callers accumulate it and call `.item()`).
+
+    symmetrical=False: sum over joints of |velocity magnitude difference|, averaged over frames and samples — on the device
+    (`ts_eval_body_loss`).  symmetrical=True (first 22 joints, `metrics.py:36-65`): of every mirrored joint pair only one side
+    counts per frame — for gt the side whose pairs moved more in that frame; for pr the reference combines the sides as
+    `left * m + right * ~m.long()` with m in {0, 1}, i.e. `~` on an INTEGER mask (-1 / -2 instead of 1 / 0): reproduced as
+    written, so that numbers stay comparable with the reference's."""
     gt, pr = _dev(gt_kps).squeeze(), _dev(pr_kps).squeeze()
     if pr.ndim == 3:
         pr = pr[None]
@@ -119,10 +148,12 @@ def lvd(gt_kps, pr_kps):
     Tl = min(int(gt.shape[0]), T)
     gt = gt[:Tl].contiguous()
     pr = pr[:, :Tl].contiguous()
+    if symmetrical:
+        return lvd_symmetric(gt, pr)
     out = torch.empty(3, dtype=torch.float64, device=pr.device)
     _lib.check(_lib.load().ts_eval_body_loss(_ctx(pr), _lib.dptr(gt), _lib.dptr(pr), B, Tl, J, J, Tl, _lib.dptr(out),
                                              _lib.stream_ptr()))
-    return float(out[0].item()) / (B * (Tl - 1))
+    return (out[0] / (B * (Tl - 1))).to(torch.float32)
 
 
 def diversity(kps):
@@ -130,11 +161,11 @@ def diversity(kps):
     k = _dev(kps)
     bs = k.shape[0]
     if bs < 2:
-        return float("nan")                     # np.mean of an empty list
+        return np.float64("nan")                # np.mean of an empty list
     k = k.reshape(bs, -1).contiguous()
     out = torch.empty(1, dtype=torch.float64, device=k.device)
     _lib.check(_lib.load().ts_eval_diversity(_ctx(k), _lib.dptr(k), bs, k.shape[1], _lib.dptr(out), _lib.stream_ptr()))
-    return float(out.item()) / (k.shape[1] * (bs * (bs - 1) // 2))
+    return np.float64(out.item() / (k.shape[1] * (bs * (bs - 1) // 2)))      # numpy scalar like the reference's np.mean
 
 
 def motion_angle_series(joints):

@@ -342,6 +342,27 @@ def main():
              joints_real=np.stack(joints_real), joints_gen=np.stack(joints_gen), beats=np.stack(beats), maac=maac,
              bc=np.float64(bc))
 
+    # ---- 5e. symmetric LVD (metrics.py:36-65): the reference's own function; it calls .cuda() on two masks, which is patched to
+    # a no-op here (no GPU in the build container) — everything else is the reference's arithmetic, its `~mask.long()` included
+    if want("lvd_symmetric"):
+        from evaluation import metrics as RM
+        rng = np.random.default_rng(67)
+        T_, J_ = 40, 22
+        gt_j = rng.standard_normal((T_, J_, 3)).astype(np.float32).cumsum(0) * 0.02
+        pr_j = (gt_j[None] + 0.05 * rng.standard_normal((3, T_ + 4, J_, 3))[:, :T_]).astype(np.float32)
+        pr_long = np.concatenate([pr_j, pr_j[:, -5:]], 1)                   # longer than gt: the reference cuts to gt's length
+        keep = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            sym = RM.LVD(torch.from_numpy(gt_j), torch.from_numpy(pr_j), symmetrical=True, weight=False)
+            sym_long = RM.LVD(torch.from_numpy(gt_j), torch.from_numpy(pr_long), symmetrical=True, weight=False)
+        finally:
+            torch.Tensor.cuda = keep
+        plain = RM.LVD(torch.from_numpy(gt_j), torch.from_numpy(pr_j), symmetrical=False, weight=False)
+        print("lvd_symmetric:", float(sym), float(sym_long), "plain", float(plain))
+        save("lvd_symmetric", gt_joints=gt_j, pr_joints=pr_j, pr_long=pr_long, lvd_sym=np.float64(sym), lvd_sym_long=np.float64(sym_long),
+             lvd_plain=np.float64(plain))
+
     # ---- 6. output assembly: demo.py:207-229 (length alignment + concat) and lower_body.part2full ------------------
     if want("assemble_full"):
         from data_utils.lower_body import part2full

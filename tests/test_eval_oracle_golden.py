@@ -48,3 +48,15 @@ def test_beat_metrics_of_the_drop_in(golden):
         ev.push_aud(torch.from_numpy(g["beats"][k]))
     np.testing.assert_allclose(ev.get_MAAC().numpy(), g["maac"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(ev.get_BCscore(), g["bc"], rtol=1e-6)
+
+
+def test_symmetric_lvd_formula_vs_reference_value():
+    """`metrics.LVD(symmetrical=True)` — the pure-torch branch of this repo's evaluation package against the value the
+    reference's own function returned (tests/golden/make_golden.py --only lvd_symmetric), its `~mask.long()` quirk included."""
+    import os
+    import torch
+    from talkshow_amd.evaluation import lvd_symmetric
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lvd_symmetric.npz"))
+    got = float(lvd_symmetric(torch.from_numpy(g["gt_joints"]), torch.from_numpy(g["pr_joints"])))
+    np.testing.assert_allclose(got, float(g["lvd_sym"]), rtol=2e-6)
+    assert abs(float(g["lvd_sym"]) - float(g["lvd_plain"])) > 1e-3          # the branch does something

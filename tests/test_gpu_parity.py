@@ -762,7 +762,15 @@ def test_evaluation_reductions_vs_reference_values(hip, golden):
     bl = E.body_loss(g["gt_joints"], g["pr_joints"])
     for k, ref in (("LVD", "lvd"), ("error", "error"), ("diverse", "diverse")):
         np.testing.assert_allclose(bl[k], g[ref], rtol=2e-5)    # reference: float32 torch arithmetic
-    np.testing.assert_allclose(M.LVD(torch.from_numpy(g["gt_joints"]), torch.from_numpy(g["pr_joints"][0])), g["lvd_single"], rtol=2e-5)
+    lv = M.LVD(torch.from_numpy(g["gt_joints"]), torch.from_numpy(g["pr_joints"][0]))
+    assert torch.is_tensor(lv) and lv.dim() == 0                      # the reference returns a tensor: its callers add them up and call .item()
+    np.testing.assert_allclose(lv.item(), g["lvd_single"], rtol=2e-5)
+    gs = golden("lvd_symmetric")                                      # the reference's symmetrical=True value (its `~mask.long()` included)
+    for key, pr in (("lvd_sym", gs["pr_joints"]), ("lvd_sym_long", gs["pr_long"])):
+        np.testing.assert_allclose(M.LVD(torch.from_numpy(gs["gt_joints"]), torch.from_numpy(pr), symmetrical=True).item(), gs[key], rtol=2e-5)
+    np.testing.assert_allclose(M.LVD(torch.from_numpy(gs["gt_joints"]), torch.from_numpy(gs["pr_joints"])).item(), gs["lvd_plain"], rtol=2e-5)
+    with pytest.raises(NotImplementedError):
+        M.LVD(torch.from_numpy(gs["gt_joints"]), torch.from_numpy(gs["pr_joints"]), weight=True)
     np.testing.assert_allclose(M.diversity(g["kps"]), g["diversity"], rtol=1e-5)
     # run-to-run determinism of the two-stage reductions (no float atomics)
     assert E.body_loss(g["gt_joints"], g["pr_joints"]) == bl and M.diversity(g["kps"]) == M.diversity(g["kps"])
