@@ -184,7 +184,28 @@ def frontend_block(w, _lib, clips):
                         f"[-> audio encoder -> PixelCNN greedy -> VQ decode]",
             "frontend_ms": t_fe * 1e3, "frontend_ms_per_32_clips": t_fe * 1e3 * 32 / clips,
             "wav_to_poses_ms": t_all * 1e3, "features_to_poses_ms": t_body * 1e3,
-            "frontend_share_of_wav_to_poses": t_fe / t_all}
+            "frontend_share_of_wav_to_poses": t_fe / t_all,
+            "stability": wav_in_stability(w, _lib, wav[:32].cpu().numpy(), ids[:32])}
+
+
+def wav_in_stability(w, _lib, wav16, ids):
+    """Outside any timed region: do the greedy codes depend on WHICH arithmetic produced the MFCC rows?  The same resampled
+    waveforms go through the device MFCC (fp32 DFT-as-GEMM, `ts_mfcc_forward`) and through the float64 host twin
+    (`frontend.mfcc_float64`); both feature sets then run the same greedy body pass.  Reported: the largest MFCC difference,
+    codes that differ (of clips x 150), clips with any difference, the largest pose difference."""
+    from talkshow_amd import frontend as FE
+    from talkshow_amd.modules import MFCC
+    n = len(wav16)
+    x22 = np.stack([FE.resample_sinc_hann(x[None], 16000, 22000)[0] for x in wav16])          # one resampler for both arms
+    dev = MFCC(22000, 22000, 30)(torch.from_numpy(x22).cuda())
+    twin = np.stack([FE.mfcc_float64(x, 22000, hop_length=734).T for x in x22])                # (n, 300, 64) float64
+    err = float(np.abs(dev.cpu().numpy().astype(np.float64) - twin).max())
+    c0, p0 = w.generate_batch(dev, ids, mode=_lib.TS_SAMPLE_GREEDY)
+    c1, p1 = w.generate_batch(torch.from_numpy(twin.astype(np.float32)).cuda(), ids, mode=_lib.TS_SAMPLE_GREEDY)
+    diff = (c0 != c1).cpu().numpy()
+    return {"clips": n, "mfcc_max_abs_err_vs_float64": err, "mfcc_max_abs": float(np.abs(twin).max()),
+            "codes_differing": int(diff.sum()), "codes_total": int(diff.size), "clips_with_a_difference": int(diff.reshape(n, -1).any(1).sum()),
+            "max_pose_delta": float((p0 - p1).abs().max().item())}
 
 
 def diversity_block(w, _lib, mfcc1):

@@ -188,6 +188,21 @@ def mfcc(wave, sample_rate, n_mfcc=64, n_fft=2048, hop_length=734, n_mels=256, t
     return mfcc_from_power(power_spectrogram(wave, n_fft, hop_length), sample_rate, n_mfcc, n_fft, n_mels, top_db)
 
 
+def mfcc_float64(wave, sample_rate, n_mfcc=64, n_fft=2048, hop_length=734, n_mels=256, top_db=80.0):
+    """`mfcc` above carried out in float64 from the (float32) samples on: the yardstick for what fp32 arithmetic costs in the
+    device front-end (bench.py `frontend.stability`, tests/test_gpu_parity.py::test_wav_in_code_stability).  -> (n_mfcc, T) float64."""
+    x = np.pad(np.asarray(wave, dtype=np.float64), (n_fft // 2, n_fft // 2), mode="reflect")
+    T = 1 + (x.shape[0] - n_fft) // hop_length
+    frames = np.lib.stride_tricks.sliding_window_view(x, n_fft)[::hop_length][:T]
+    window = 0.5 - 0.5 * np.cos(2.0 * math.pi * np.arange(n_fft) / n_fft)
+    spec = np.fft.rfft(frames * window[None, :], axis=1)
+    power = spec.real ** 2 + spec.imag ** 2
+    mel = power @ melscale_fbanks(n_fft // 2 + 1, 0.0, float(sample_rate // 2), n_mels, sample_rate).astype(np.float64)
+    db = 10.0 * np.log10(np.maximum(mel, 1e-10))
+    db = np.maximum(db, db.max() - top_db)
+    return np.ascontiguousarray((db @ create_dct(n_mfcc, n_mels).astype(np.float64)).T)
+
+
 def _hop(fps):
     if fps == 15:
         return 1467

@@ -669,6 +669,28 @@ def test_device_mfcc_vs_host_restatement(hip, tmp_path):
     np.testing.assert_allclose(a, b, atol=0.05, rtol=2e-4)
 
 
+def test_wav_in_code_stability(hip, tmp_path):
+    """device MFCC rows (fp32 DFT-as-GEMM) vs the float64 host twin on the same resampled waveforms — the MFCC
+    difference stays under 2e-3 (coefficients are O(10..200)) and NOT ONE of the 32 x 150 greedy codes changes, for noise clips
+    (the bench's synthetic audio) and for speech-like clips (amplitude-modulated harmonics + noise, 50 dB of dynamic range)."""
+    import bench
+    _lib, lib, ctx = hip
+    w, _ = bench.build_models(0)
+    ids = torch.from_numpy(synth.speaker_ids(32)).cuda()
+    rng = np.random.default_rng(12)
+    t = np.arange(160000) / 16000.0
+    speechy = []
+    for k in range(32):
+        f0 = 90.0 + 6.0 * k
+        env = np.clip(np.sin(2 * np.pi * (2.0 + 0.1 * k) * t + k), 0, None) ** 2
+        x = sum(np.sin(2 * np.pi * f0 * h * t + h) / h for h in range(1, 12)) * env * 0.08 + 0.003 * rng.standard_normal(t.size)
+        speechy.append(x.astype(np.float32))
+    for name, wav in (("noise", synth.wav16(7000, 32, 160000)), ("speech-like", np.stack(speechy))):
+        s = bench.wav_in_stability(w, _lib, wav, ids)
+        assert s["mfcc_max_abs_err_vs_float64"] <= 2e-3, (name, s)
+        assert s["codes_differing"] == 0 and s["max_pose_delta"] == 0.0, (name, s)
+
+
 @pytest.mark.parametrize("env", [{"TS_SKINNY_V": "0"}, {"TS_NO_GRAPH": "1"}, {"TS_SKINNY_NT": "32"},
                                  {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"},
                                  {"TS_SKINNY_TILED": "0", "TS_WITH_CLIPS": "1"}, {"TS_PIX_DEFER_P": "0", "TS_WITH_CLIPS": "1"},
