@@ -94,26 +94,50 @@ def test_conv_tile_shapes_agree(hip):
         assert np.array_equal(o, outs[2]), f"tile {tile} differs from the 64x64 tile"
 
 
+def _fma32(a, b, c):
+    """float32 fma emulated through float64 (the product is exact there; the second rounding differs from a true fma only in
+    ~2^-29 of the cases)."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
 @pytest.mark.parametrize("M,ncode,dim", [(1, 128, 64), (13, 2048, 64), (2400, 2048, 64)])
 def test_op_vq_argmin(hip, M, ncode, dim):
+    """Index work is bit-exact: (a) on operands whose every product and partial sum is exactly representable in fp32 (multiples
+    of 1/64 in [-4, 4]) the distances are exact whatever the summation order, so the indices must equal numpy's float64 argmin,
+    exact ties -> lowest index, no exceptions; (b) on random fp32 operands the indices must equal the argmin of the distances
+    recomputed IN THE KERNEL'S ORDER (|x|^2 and |e|^2 as sequential fma chains, the dot product as a sequential fma chain,
+    (|x|^2 + |e|^2) - 2 dot), again without exceptions."""
     _lib, lib, ctx = hip
     rng = np.random.default_rng(M)
+
+    def run(x, cb):
+        idx = torch.empty(M, dtype=torch.int64, device="cuda")
+        xd, cbd = dev(x), dev(cb)           # keep the device tensors alive across the call
+        _lib.check(lib.ts_op_vq_argmin(ctx, _lib.dptr(xd), M, _lib.dptr(cbd), ncode, dim, _lib.dptr(idx), None))
+        return idx.cpu().numpy()
+
+    # (a) exactly representable arithmetic, with a block of duplicated codes (exact ties everywhere)
+    xq = (rng.integers(-256, 257, (M, dim)) / 64.0).astype(np.float32)
+    cq = (rng.integers(-256, 257, (ncode, dim)) / 64.0).astype(np.float32)
+    cq[ncode // 2:ncode // 2 + 16] = cq[5:21]
+    xq[0] = cq[9]
+    d64 = (xq.astype(np.float64) ** 2).sum(1, keepdims=True) + (cq.astype(np.float64) ** 2).sum(1)[None] - 2.0 * xq.astype(np.float64) @ cq.astype(np.float64).T
+    np.testing.assert_array_equal(run(xq, cq), d64.argmin(1))
+    # (b) random operands, distances in the kernel's order
     x = rng.standard_normal((M, dim)).astype(np.float32)
     cb = rng.standard_normal((ncode, dim)).astype(np.float32)
     cb[7] = cb[3]                       # an exact tie between codes 3 and 7 ...
     x[0] = cb[3]                        # ... which row 0 hits: lowest index must win
-    idx = torch.empty(M, dtype=torch.int64, device="cuda")
-    xd, cbd = dev(x), dev(cb)           # keep the device tensors alive across the call
-    _lib.check(lib.ts_op_vq_argmin(ctx, _lib.dptr(xd), M, _lib.dptr(cbd), ncode, dim, _lib.dptr(idx), None))
-    ref = O.vq_get_code_indices(x, cb)
-    got = idx.cpu().numpy()
+    xsq, csq = np.zeros(M, np.float32), np.zeros(ncode, np.float32)
+    dot = np.zeros((M, ncode), np.float32)
+    for c in range(dim):
+        xsq = _fma32(x[:, c], x[:, c], xsq)
+        csq = _fma32(cb[:, c], cb[:, c], csq)
+        dot = _fma32(x[:, c:c + 1], cb[None, :, c], dot)
+    d = (xsq[:, None] + csq[None, :]) - np.float32(2.0) * dot
+    got = run(x, cb)
     assert got[0] == 3
-    mism = np.nonzero(got != ref)[0]
-    # a different fp32 summation order may flip near-ties only; verify each flip is a near-tie
-    d = (x ** 2).sum(1, keepdims=True) + (cb ** 2).sum(1)[None] - 2 * x @ cb.T
-    for m in mism:
-        assert abs(d[m, got[m]] - d[m, ref[m]]) < 1e-4 * max(1.0, abs(d[m, ref[m]]))
-    assert len(mism) <= max(1, M // 1000)
+    np.testing.assert_array_equal(got, d.argmin(1))
 
 
 @pytest.mark.parametrize("M,K,N,relu", [(32, 256, 512, 0), (64, 512, 256, 1), (3, 64, 128, 0), (32, 512, 2048, 0),
