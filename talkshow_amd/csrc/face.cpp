@@ -233,7 +233,8 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
         if (L[i] < f->fc_k[i]) return fail("ts_face_generate: audio too short (needs >= 400 samples)");
     }
     const int Tp = round_up(T, 32);
-    if (Tp > 512) return fail("ts_face_generate: at most 512 frames per call (softmax row buffer)");
+    if ((long)B * f->HEADS * T * Tp > (1l << 31) - 1 || Tp > 60000)
+        return fail("ts_face_generate: B * heads * frames^2 exceeds the attention score buffer's 2^31 entries: split the call");
     const long M = (long)B * T;
     ts_face::Work &w = f->work(s);
     const size_t F = sizeof(float);

@@ -214,9 +214,29 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ p
         if (c < ld) r[c] = v[i] * inv;
     }
 }
+// rows longer than 512 (clips beyond ~17 s: the reference takes a wav of any length, smplx_face.py:169-218): the row is walked
+// three times (max, sum of exponentials, normalised write) instead of being held in registers; a lane visits its elements in
+// the same order and the lanes are combined in the same order as above, so a row of <= 512 would give the same bits
+__global__ __launch_bounds__(256) void softmax_rows_long_kernel(float *__restrict__ p, long rows, int S, int ld, float scale) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float *r = p + m * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < S; c += 64) mx = fmaxf(mx, r[c] * scale);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+    for (int c = lane; c < S; c += 64) sum += expf(r[c] * scale - mx);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float inv = 1.0f / sum;
+    for (int c = lane; c < ld; c += 64) r[c] = c < S ? expf(r[c] * scale - mx) * inv : 0.f;
+}
 hipError_t launch_softmax_rows(float *p, long rows, int S, int ld, float scale, hipStream_t s) {
-    if (ld > 512 || S > ld) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p, rows, S, ld, scale);
+    if (S > ld || S < 1) return hipErrorInvalidValue;
+    if (ld <= 512) hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p, rows, S, ld, scale);
+    else hipLaunchKernelGGL(softmax_rows_long_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p, rows, S, ld, scale);
     return hipGetLastError();
 }
 

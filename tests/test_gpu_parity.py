@@ -570,6 +570,25 @@ def test_wrapper_face(hip, golden, tmp_path):
     assert w.each_dim == [3, 72, 90, 100]
 
 
+def test_face_one_minute_clip_vs_oracle(hip):
+    """A 60 s clip in ONE call (960 000 samples -> 1 800 frames: attention rows of 1 824 entries, beyond the 512 the softmax
+    kernel keeps in registers) against the CPU oracle — the reference's `infer_on_audio` takes a wav of any length
+    (`smplx_face.py:169-218`) — and through the wrapper; a 20 s clip (600 frames) rides along as the first size past the old cap."""
+    from oracle import face_oracle as FO
+    from talkshow_amd.modules import FaceGenerator
+    sd = synth.face_state_dict(seed=5)
+    m = FaceGenerator().cuda()
+    m.load_state_dict(synth.to_torch(sd))
+    for seconds in (20, 60):
+        N, frames = 16000 * seconds, 30 * seconds
+        wav = synth.wav16(43 + seconds, 1, N)
+        ids = np.eye(4, dtype=np.float32)[[2]]
+        out = m.run(wav, ids, frames).cpu().numpy()
+        ref = FO.face_generator(wav, ids, sd, frames)
+        assert out.shape == ref.shape == (1, frames, 103)
+        np.testing.assert_allclose(out, ref, atol=1e-4, rtol=0)
+
+
 def test_face_full_length_vs_oracle(hip):
     """A full 10 s clip (160 000 samples -> 499 conv frames -> 300 output frames) against the CPU oracle, plus batch
     independence and run-to-run determinism at B=3."""
