@@ -10,7 +10,7 @@ from nets.base import TrainWrapperBaseClass, resolve_device
 from talkshow_amd import _lib
 from talkshow_amd.frontend import get_mfcc_sepa, get_mfcc_ta
 from talkshow_amd.modules import AudioEncoder, GatedPixelCNN as pixelcnn, VQVAE as s2g_body, _index_tensor
-from talkshow_amd.pose_index import c_index_3d
+from talkshow_amd.pose_index import c_index_3d, c_index_6d
 
 
 class TrainWrapper(TrainWrapperBaseClass):
@@ -25,8 +25,6 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.device = resolve_device(args.gpu)
         self.global_step = self.epoch = 0
         self.convert_to_6d, self.expression = pose_cfg.convert_to_6d, pose_cfg.expression
-        if self.convert_to_6d:   # would be GatedPixelCNN(dim 512, 10 layers); no shipped config uses it
-            raise NotImplementedError("convert_to_6d=true is not used by any shipped config (SURVEY.md §2)")
         self.init_params()
         self.num_classes = 4
         self.audio = True
@@ -35,7 +33,10 @@ class TrainWrapper(TrainWrapperBaseClass):
         # the four networks of `smplx_body_pixel.py:46-57`, same hyper-parameters
         self.audioencoder = AudioEncoder(in_dim=64, num_hiddens=256, num_residual_layers=2,
                                          num_residual_hiddens=256).to(self.device)
-        self.generator = pixelcnn(2048, 256, 15, self.num_classes, self.audio, self.bh_model).to(self.device)
+        # 6-D rotations double every pose width (39 / 90 -> 78 / 180 modelled dims) and the reference then trades depth for
+        # width in the code predictor (`smplx_body_pixel.py:48-52`)
+        dim, layer = (512, 10) if self.convert_to_6d else (256, 15)
+        self.generator = pixelcnn(2048, dim, layer, self.num_classes, self.audio, self.bh_model).to(self.device)
         vq_kw = dict(embedding_dim=64, num_embeddings=model_cfg.code_num, num_hiddens=1024, num_residual_layers=2,
                      num_residual_hiddens=512)
         self.g_body = s2g_body(self.each_dim[1], **vq_kw).to(self.device)
@@ -46,7 +47,7 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.g_hand.load_state_dict(vq_ckpt['g_hand'])
 
         self.discriminator = None
-        self.c_index = c_index_3d
+        self.c_index = c_index_6d if self.convert_to_6d else c_index_3d
         super().__init__(args, config)
 
     def init_optimizer(self):

@@ -12,6 +12,9 @@ _all = np.ones(165)
 _all[FIX_INDEX_3D] = 0
 c_index_3d = np.asarray([i for i, v in enumerate(_all) if v == 1])
 assert c_index_3d.shape == (129,)
+# the same selection on 6-D rotation rows (`lower_body.py:58-65`): dim i of the axis-angle layout owns dims 2 i, 2 i + 1
+c_index_6d = np.asarray([j for i in c_index_3d for j in (2 * i, 2 * i + 1)])
+assert c_index_6d.shape == (258,)
 
 
 # The fixed lower-body block `part2full` inserts (data_utils/lower_body.py:4-8, values quoted from there; 33 = 15 + 6 + 6 + 6)

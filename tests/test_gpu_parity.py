@@ -482,6 +482,37 @@ def test_full_size_properties(hip, tmp_path):
     np.testing.assert_array_equal(body.cpu().numpy(), p1[..., :39].cpu().numpy())
 
 
+def test_wrapper_body_pixel_convert_to_6d(hip, tmp_path):
+    """`convert_to_6d=true` (`smplx_body_pixel.py:48-52`): 6-D rotations double the modelled widths (78 body + 180 hand dims) and
+    the code predictor becomes GatedPixelCNN(2048, dim 512, 10 layers).  No shipped config uses it and the reference holds no
+    golden for it: the wrapper's result on short clips is checked against the oracle (full-grid numpy restatement, pinned to
+    the reference on the 3-d shapes) built from the same state dicts."""
+    from nets.init_model import init_model
+    from talkshow_amd import _lib
+    from talkshow_amd.config import Object
+    from talkshow_amd.pose_index import c_index_6d
+    sd_b = synth.vqvae_state_dict(seed=9, in_dim=78)
+    sd_h = synth.vqvae_state_dict(seed=9, in_dim=180, salt=1)
+    vq_path = str(tmp_path / "vq6d.pth")
+    torch.save({"generator": {"g_body": synth.to_torch(sd_b), "g_hand": synth.to_torch(sd_h)}}, vq_path)
+    cfg = json.load(open(os.path.join(REPO, "config", "body_pixel.json")))
+    cfg["Model"]["vq_path"] = vq_path
+    cfg["Data"]["pose"]["convert_to_6d"] = True
+    w = init_model("s2g_body_pixel", argparse.Namespace(gpu=0, infer=True), Object(cfg))
+    assert w.each_dim[1:3] == [78, 180] and w.generator.dim == 512 and w.generator.n_layers == 10 and len(w.c_index) == 258
+    assert np.array_equal(w.c_index, c_index_6d)
+    sd_p = synth.pixelcnn_state_dict(seed=9, dim=512, n_layers=10)
+    sd_a = synth.audioencoder_state_dict(seed=9)
+    w.load_state_dict({"generator": synth.to_torch(sd_p), "audioencoder": synth.to_torch(sd_a)})
+    B, T = 3, 24                                                     # 6 code rows: the oracle recomputes the whole grid per position
+    mf, ids = synth.mfcc_features(19, B, T), synth.speaker_ids(B)
+    codes, poses = w.generate_batch(mf, ids, mode=_lib.TS_SAMPLE_GREEDY)
+    rc, rp, _ = O.body_pixel_infer(mf, ids, sd_a, sd_p, sd_b, sd_h, n_layers=10)
+    assert poses.shape == (B, T, 258)
+    np.testing.assert_array_equal(codes.cpu().numpy(), rc)
+    np.testing.assert_allclose(poses.cpu().numpy(), rp, atol=1e-4, rtol=0)
+
+
 def test_golden_clips_inside_baseline_batches(hip, golden, tmp_path):
     """The two reference-golden clips (body_e2e_full, B=2) embedded at arbitrary slots of a BASELINE batch of 32, of a
     coalesced chain of 128 clips (4 batches in one launch sequence, 64 x 32 split-K tiles), of the bench's 256-clip pass (the
