@@ -13,6 +13,11 @@ from talkshow_amd.modules import AudioEncoder, GatedPixelCNN as pixelcnn, VQVAE 
 from talkshow_amd.pose_index import c_index_3d, c_index_6d
 
 
+def _fresh_seed():
+    """A Philox key drawn from torch's generator (so `torch.manual_seed` makes sampling reproducible, as in the reference)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
 class TrainWrapper(TrainWrapperBaseClass):
     '''
     a wrapper receiving audio features and generating motion (reference: a wrapper receving a batch from data_utils
@@ -80,7 +85,7 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.g_hand.decode_nlc(latents[..., 1].contiguous(), out=out, col0=self.each_dim[1])
         return out
 
-    def generate_batch(self, mfcc, ids, mode=_lib.TS_SAMPLE_PHILOX, uniforms=None, seed=0, clip_index0=0):
+    def generate_batch(self, mfcc, ids, mode=_lib.TS_SAMPLE_PHILOX, uniforms=None, seed=None, clip_index0=0):
         """Batched device entry (one call into the C ABI): mfcc (B,T,64), ids (B,) -> codes (B,H,2), poses (B,4H,129).
 
         This is what `infer_on_audio` runs after the front-end, for B different clips; bench.py and the multi-GPU
@@ -96,6 +101,8 @@ class TrainWrapper(TrainWrapperBaseClass):
             ids = ids.repeat(B)
         if ids.numel() != B:
             raise ValueError(f"ids must hold 1 or B={B} speaker indices, got {ids.numel()}")
+        if seed is None:   # like the reference, which draws from torch's generator on every call: repeated calls differ
+            seed = _fresh_seed()
         codes = torch.zeros((B, H, 2), dtype=torch.int64, device=dev)
         poses = torch.empty((B, 4 * H, self.each_dim[1] + self.each_dim[2]), dtype=torch.float32, device=dev)
         if uniforms is not None:
@@ -106,7 +113,7 @@ class TrainWrapper(TrainWrapperBaseClass):
             _lib.dptr(codes), _lib.dptr(poses), _lib.stream_ptr()))
         return codes, poses
 
-    def generate_batches(self, mfccs, ids_list, mode=_lib.TS_SAMPLE_PHILOX, seed=0, clip_index0=0):
+    def generate_batches(self, mfccs, ids_list, mode=_lib.TS_SAMPLE_PHILOX, seed=None, clip_index0=0):
         """Coalesced execution of several independent batches (the serving path): the batches' clips are stacked and
         the autoregressive chain runs ONCE over all of them, so a stage's weights are streamed once for all batches
         in flight instead of once per batch (a chain stage is latency-bound below ~64 clips).  Results are bit-identical
@@ -158,7 +165,7 @@ class TrainWrapper(TrainWrapperBaseClass):
             mode = _lib.TS_SAMPLE_UNIFORMS
         seed = kwargs.get('seed', None)
         if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            seed = _fresh_seed()
 
         with torch.no_grad():
             aud_feat = aud_feat.permute(0, 2, 1)                      # (B, T, 64)
@@ -167,8 +174,13 @@ class TrainWrapper(TrainWrapperBaseClass):
                 # prefix it re-runs in full (`:260-269`); here the second part continues the first part's row cache
                 self.audioencoder.eval()
                 session = self.open_stream(id, B, max_frames=max(gap, aud_feat.shape[1] - gap))
-                part0 = session.push(aud_feat[:, :gap], mode=mode, seed=seed)
-                part1 = session.push(aud_feat[:, gap:], mode=mode, seed=seed)
+                u0 = u1 = None
+                if uniforms is not None:                                 # (B, H, 2) for the whole clip: split at the seam's code row
+                    uniforms = torch.as_tensor(uniforms, dtype=torch.float32)
+                    h0 = gap // 4
+                    u0, u1 = uniforms[:, :h0].contiguous(), uniforms[:, h0:].contiguous()
+                part0 = session.push(aud_feat[:, :gap], mode=mode, seed=seed, uniforms=u0)
+                part1 = session.push(aud_feat[:, gap:], mode=mode, seed=seed, uniforms=u1)
                 session.close()
                 pred_poses = torch.cat([part0, part1], dim=1).cpu().numpy()
             else:
@@ -187,11 +199,13 @@ class TrainWrapper(TrainWrapperBaseClass):
         decoders on its own (their receptive fields are not carried across chunks)."""
         return BodyStream(self, id, B, max_frames)
 
-    def infer(self, aud_feat, frame, id, B, pre_latents=None, pre_audio=None, pre_pose=None, mode=None, seed=0):
+    def infer(self, aud_feat, frame, id, B, pre_latents=None, pre_audio=None, pre_pose=None, mode=None, seed=None):
         """smplx_body_pixel.py:291-304 (continuity helper, reference call shape): returns latents, audio (B,256,H,2),
         body, hand (B,C,T); `pre_latents` / `pre_audio` are re-run as a prefix exactly like the reference does."""
         if mode is None:
             mode = _lib.TS_SAMPLE_PHILOX
+        if seed is None:
+            seed = _fresh_seed()
         rows = self.audioencoder.forward_nlc(aud_feat)                                    # (B,H,256)
         audio = rows.transpose(1, 2).unsqueeze(dim=-1).repeat(1, 1, 1, 2)
         pre_rows = pre_audio[..., 0].transpose(1, 2).contiguous() if pre_audio is not None else None
@@ -216,14 +230,15 @@ class BodyStream:
         if id is None:
             id = torch.tensor([0])
         self.pix = wrapper.generator.open_stream(id, self.B, max(1, int(max_frames) // 4))
+        self.seed = _fresh_seed()          # one stream of random numbers per session unless push() is given a seed
 
     @property
     def frames(self):
         return 4 * self.pix.rows
 
-    def push(self, mfcc, mode=_lib.TS_SAMPLE_PHILOX, seed=0, clip_index0=0, uniforms=None):
+    def push(self, mfcc, mode=_lib.TS_SAMPLE_PHILOX, seed=None, clip_index0=0, uniforms=None):
         rows = self.w.audioencoder.forward_nlc(mfcc)                      # (B, T//4, 256), this chunk alone
-        codes = self.pix.step(rows, mode=mode, uniforms=uniforms, seed=seed, clip_index0=clip_index0)
+        codes = self.pix.step(rows, mode=mode, uniforms=uniforms, seed=self.seed if seed is None else seed, clip_index0=clip_index0)
         return self.w._decode_pair(codes)
 
     def close(self):

@@ -175,7 +175,9 @@ struct RunCfg {
 inline RunCfg one_shot_cfg(int B, int H, int H0, int mode, const float *uniforms, uint64_t seed, int64_t clip0, int64_t *codes,
                            float *logits, ts_pixelcnn::Work *w) {
     const int Htot = H0 + H;
-    return RunCfg{B, H, H0, Htot, mode, uniforms, seed, clip0, codes, logits, nullptr, w, Htot, 0, Htot, H0, H0, 0, Htot};
+    // Philox position of code (r, j) = 2 r + j with r counted from the first PREFIX row: a call that continues another one
+    // behind its codes (`infer(chunk1, pre_latents=chunk0 codes)`) draws the next numbers of the stream, not chunk 0's again
+    return RunCfg{B, H, H0, Htot, mode, uniforms, seed, clip0, codes, logits, nullptr, w, Htot, 0, Htot, H0, 0, 0, Htot};
 }
 
 SkinnyParams base_params(int M, int N, int epi) {

@@ -181,6 +181,7 @@ int ts_smplx_forward(ts_smplx *m, const float *betas, int betas_per_row, const f
                      float *joints, float *verts, void *stream) {
     if (!m || !betas || !rows || !joints) return fail("ts_smplx_forward: null argument");
     if (N < 1 || row_ld < 1) return fail("ts_smplx_forward: bad shape");
+    if (N > 0x7fffffff) return fail("ts_smplx_forward: more than 2^31 - 1 frames in one call");
     if (verts && !m->with_vertices) return fail("ts_smplx_forward: model was created without the full-mesh matrices (with_vertices = 0)");
     hipStream_t s = (hipStream_t)stream;
     ts_ctx *ctx = m->ctx;

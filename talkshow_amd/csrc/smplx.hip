@@ -172,8 +172,12 @@ hipError_t launch_smplx_rigid_chain(const float *rot, const float *jrest, int jr
 }
 hipError_t launch_smplx_skin(const float *vposed, int vp_ld, const float *A, int J, const int *bone, const float *wgt, int KW,
                              int U, long N, float *out, long out_frame_stride, hipStream_t s) {
-    hipLaunchKernelGGL(smplx_skin, dim3((U + 127) / 128, (unsigned)N), dim3(128), 0, s, vposed, vp_ld, A, J, bone, wgt, KW, U, out,
-                       out_frame_stride);
+    // frames ride on grid.y (limit 65 535): longer runs (256 clips x 300 frames) go out in slices
+    for (long n0 = 0; n0 < N; n0 += 65535) {
+        const long nn = N - n0 < 65535 ? N - n0 : 65535;
+        hipLaunchKernelGGL(smplx_skin, dim3((U + 127) / 128, (unsigned)nn), dim3(128), 0, s, vposed + n0 * vp_ld, vp_ld,
+                           A + n0 * J * 12, J, bone, wgt, KW, U, out + n0 * out_frame_stride, out_frame_stride);
+    }
     return hipGetLastError();
 }
 hipError_t launch_smplx_joints_tail(const float *vs, long vs_frame_stride, const int *extra_map, int n_extra, const int *lmk_map,

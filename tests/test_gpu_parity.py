@@ -267,6 +267,40 @@ def test_pixelcnn_sampling_and_prefix(hip, golden):
     tail, _ = m.run(g["label"], g["aud"][:, H0:], mode=_lib.TS_SAMPLE_GREEDY, pre_codes=g["codes"][:, :H0],
                     pre_aud=g["aud"][:, :H0])
     np.testing.assert_array_equal(tail.cpu().numpy(), g["codes"][:, H0:])
+    # ... and the SAMPLED tail given the sampled head == the single sampled run: the Philox position of a code is its absolute
+    # (row, column), prefix rows included (the prefix path used to restart at position 0 and replay chunk 0's numbers)
+    tail_p, _ = m.run(g["label"], g["aud"][:, H0:], mode=_lib.TS_SAMPLE_PHILOX, seed=1234, clip_index0=10,
+                      pre_codes=got_p[:, :H0], pre_aud=g["aud"][:, :H0])
+    np.testing.assert_array_equal(tail_p.cpu().numpy(), got_p.cpu().numpy()[:, H0:])
+
+
+def test_wrapper_sampling_defaults(hip, golden, tmp_path):
+    """like the reference, sampling entry points draw from torch's generator when no seed is given (two calls differ,
+    `torch.manual_seed` reproduces them), and `infer_on_audio(continuity=True, uniforms=...)` hands the uniforms on to both parts."""
+    from nets.init_model import init_model
+    import nets.smplx_body_pixel as bp
+    g = golden("body_e2e_full")
+    w = init_model("s2g_body_pixel", argparse.Namespace(gpu=0, infer=True), _config(tmp_path))
+    w.load_state_dict({"generator": synth.to_torch(synth.pixelcnn_state_dict(seed=7)),
+                       "audioencoder": synth.to_torch(synth.audioencoder_state_dict(seed=7))})
+    torch.manual_seed(5)
+    a, _ = w.generate_batch(g["mfcc"], g["ids"])
+    b, _ = w.generate_batch(g["mfcc"], g["ids"])
+    torch.manual_seed(5)
+    a2, _ = w.generate_batch(g["mfcc"], g["ids"])
+    assert not torch.equal(a, b) and torch.equal(a, a2)
+    # continuity with injected uniforms: the two parts consume the two halves of the (B, H, 2) array
+    import pytest as _pt
+    mp = _pt.MonkeyPatch()
+    try:
+        gap = 60
+        mp.setattr(bp, "get_mfcc_sepa", lambda *a_, **k_: (g["mfcc"][0].copy(), gap))
+        u = O.philox_uniforms(9, 0, 1, 75)
+        out = w.infer_on_audio("clip.wav", id=torch.tensor([1]), fps=30, continuity=True, uniforms=u)
+        out2 = w.infer_on_audio("clip.wav", id=torch.tensor([1]), fps=30, continuity=True, uniforms=u)
+        assert out.shape == (1, 300, 129) and np.array_equal(out, out2)
+    finally:
+        mp.undo()
 
 
 def test_pixelcnn_streaming_equals_one_call(hip, golden):
