@@ -153,10 +153,36 @@ def face_block(local):
     _lib.check(lib.ts_prof_read(ctx, msf, nf, flf, 1))
     _lib.check(lib.ts_prof_enable(ctx, 0))
     ach = flf[0] / (msf[0] * 1e-3) / 1e12
-    return {"workload": "BASELINE configs[2]: face generator, batch=64 x 10 s @16 kHz, 103 params @30 fps",
-            "frames_per_s": B * T / dt, "ms_per_batch": dt * 1e3,
-            "conv_gemm_f32": {"launches": nf[0], "ms": msf[0], "achieved_TFLOPs": ach, "frac_of_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS},
-            "other_kernels_ms": msf[2]}
+    out = {"workload": "BASELINE configs[2]: face generator, batch=64 x 10 s @16 kHz, 103 params @30 fps",
+           "frames_per_s": B * T / dt, "ms_per_batch": dt * 1e3,
+           "conv_gemm_f32": {"launches": nf[0], "ms": msf[0], "achieved_TFLOPs": ach, "frac_of_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS},
+           "other_kernels_ms": msf[2]}
+    # OPT-IN split-bf16 plans beside the fp32 line (never the headline; dtype of the main line stays f32): speed on the same batch,
+    # error of the same two reference-golden clips the parity tests use (tests/golden/face_10s.npz), embedded in a batch of 64
+    try:
+        g = np.load(os.path.join(REPO, "tests", "golden", "face_10s.npz"))
+        seed, gb, gn = (int(v) for v in g["wav_seed"])
+        gwav = torch.from_numpy(synth.wav16(seed, gb, gn)).cuda()
+        gids = torch.from_numpy(g["ids"]).cuda()
+        m.load_state_dict(synth.to_torch(synth.face_state_dict(seed=7)))      # the golden's weights (timing does not depend on them)
+        split = {"fp32_max_abs_err_vs_reference_golden": float((m.run(gwav, gids, T).cpu() - torch.from_numpy(g["out"])).abs().max())}
+        for products in (6, 3):
+            m.set_arith(products)
+            m.run(wav, ids, T)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                m.run(wav, ids, T)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / K
+            err = float((m.run(gwav, gids, T).cpu() - torch.from_numpy(g["out"])).abs().max())
+            split[f"bf16x{products}"] = {"terms": products, "frames_per_s": B * T / dts, "ms_per_batch": dts * 1e3,
+                                         "speedup_vs_fp32": dt / dts, "max_abs_err_vs_reference_golden": err}
+        m.set_arith(0)
+        out["split_bf16"] = split
+    except Exception as e:
+        out["split_bf16"] = {"error": repr(e)}
+    return out
 
 
 def frontend_block(w, _lib, clips):

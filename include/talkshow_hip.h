@@ -145,6 +145,11 @@ void ts_face_destroy(ts_face *face);
  * hidden_dev optional (B,frames,768): the wav2vec2 last_hidden_state (parity tests). */
 int ts_face_generate(ts_face *face, const float *wav_dev, int B, int N, int frames, const float *id_dev, float *out_dev,
                      float *hidden_dev, void *stream);
+/* OPT-IN arithmetic plan of the generator's GEMMs (no counterpart in the reference, which runs fp32 throughout): 0 = fp32 MFMA,
+ * the default and the path every parity claim is made on; 3 / 6 = split-bf16: each fp32 operand becomes 2 / 3 bf16 terms and a
+ * product 3 / 6 exact bf16 products accumulated in fp32 (csrc/conv_gemm_split.hip; measured error vs the reference golden in
+ * DESIGN.md).  The first feature convolution, attention, LayerNorms and soft-max stay fp32.  Never applies to the body path. */
+int ts_face_set_arith(ts_face *face, int bf16_products);
 
 /* ---- audio front-end on the device: get_mfcc_ta (data_utils/utils.py:148-231) = torchaudio Resample(sr_in -> sr_out)
  * + MFCC(n_mfcc=64, n_fft=2048, n_mels=256, hop = 734 (fps 30) | 1467 (fps 15), mel_scale='htk').  torchaudio is

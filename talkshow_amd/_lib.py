@@ -54,6 +54,7 @@ SIGNATURES = {
     "ts_face_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, C.POINTER(_vp)]),
     "ts_face_destroy": (None, [_vp]),
     "ts_face_generate": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ts_face_set_arith": (_i, [_vp, _i]),
     "ts_mfcc_create": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
     "ts_mfcc_destroy": (None, [_vp]),
     "ts_mfcc_num_frames": (_i, [_vp, C.c_long]),

@@ -92,6 +92,8 @@ struct ts_face {
     ConvLayer fn[3], fn0res, dec[2][3], fin[2];
     LNp fn_ln[3], dec_ln[2][3];
 
+    int split_planes = 0;   // 0: fp32 MFMA (default, the parity path); 2 / 3: opt-in split-bf16 GEMMs (ts_face_set_arith)
+
     struct Work {
         DevBuf A, Bf, part, stats, X512, H, H2, TMP, QKV, SC, VT, ATT, FF, X320, Y1, Y2, R, D1, D2;
     };
@@ -216,6 +218,17 @@ int ts_face_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int n_layers, int n
 
 void ts_face_destroy(ts_face *f) { delete f; }
 
+// Arithmetic plan of the generator's GEMMs (feature convolutions 1..6, projections, positional conv, transformer-block GEMMs,
+// LN-conv heads): 0 = fp32 MFMA (default: what every parity claim is made on), 3 / 6 = split-bf16 with three / six bf16 products
+// per fp32 product (conv_gemm_split.hip).  Layer 0 of the feature extractor (K = 10, VALU), the attention products, LayerNorms
+// and soft-max stay fp32 in every plan.
+int ts_face_set_arith(ts_face *f, int bf16_products) {
+    if (!f) return fail("ts_face_set_arith: null argument");
+    if (bf16_products != 0 && bf16_products != 3 && bf16_products != 6) return fail("ts_face_set_arith: 0 (fp32), 3 or 6 bf16 products");
+    f->split_planes = bf16_products == 0 ? 0 : (bf16_products == 3 ? 2 : 3);
+    return 0;
+}
+
 // s2g_face.Generator.forward, eval (s2g_face.py:196-224): wav (B,N) fp32, id (B,num_classes) fp32 (one-hot or zeros,
 // smplx_face.py:205-208) -> out (B,frames,103); hidden_out optional (B,frames,768) = wav2vec2 last_hidden_state.
 int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, const float *id, float *out, float *hidden_out,
@@ -263,7 +276,7 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
     auto conv = [&](const ConvLayer &Ly, const float *x, int ldx, int Bc, int Lin, int Lout, int stride, const float *res,
                     int ldr, float *o, int ldo, int col0, int nstore, int act) -> int {
         params_for(Ly, x, ldx, Bc, Lin, Lout, stride, res, ldr, o, ldo, col0, nstore, act, &p);
-        return run_conv(ctx, p, 0, s);
+        return run_conv(ctx, p, f->split_planes ? 20 + f->split_planes : 0, s);
     };
     auto ln = [&](const float *x, int C, const LNp &q, const float *post, int relu, float *o) -> int {
         MiscScope ms(ctx, s);
@@ -319,7 +332,7 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
         G.out = w.TMP.f();
         G.nseg = 1;
         G.seg[0] = ConvSeg{-(f->POSK / 2), 0, 64, f->POSK};
-        TS_TRY(run_conv(ctx, p, 0, s));
+        TS_TRY(run_conv(ctx, p, f->split_planes ? 20 + f->split_planes : 0, s));
     }
     TS_TRY(ln(w.TMP.f(), HID, f->enc_ln, nullptr, 0, w.H.f()));
     // ---- transformer layers (post-LN) ----

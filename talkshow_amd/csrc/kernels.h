@@ -52,6 +52,9 @@ struct ConvParams {
 
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 (BK 64), 6 = 160x128, 7 = 96x128 (for tuning / tests)
 hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream);
+// the same convolution on the bf16 matrix cores with fp32 operands split into `planes` bf16 terms (2: three products, ~2^-16;
+// 3: six products, fp32 grade) — conv_gemm_split.hip; an opt-in plan for tolerance-only GEMMs (the face generator)
+hipError_t launch_conv_gemm_split(const ConvParams &p, int planes, hipStream_t stream);
 double conv_gemm_flops(const ConvParams &p);
 
 // ------------------------------------------------------------------------------------------------

@@ -103,7 +103,8 @@ int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s) {
             ctx->prof.recs.back().flops = conv_gemm_flops(p);
         }
     }
-    hipError_t e = launch_conv_gemm(p, tile, s);
+    // tile ids 22 / 23: the opt-in split-bf16 plan with 2 / 3 planes (conv_gemm_split.hip); everything else: fp32 MFMA
+    hipError_t e = (tile == 22 || tile == 23) ? launch_conv_gemm_split(p, tile - 20, s) : launch_conv_gemm(p, tile, s);
     if (ctx->prof.on) ctx->prof.end(s);
     if (e != hipSuccess) return fail(std::string("conv_gemm launch: ") + hipGetErrorString(e));
     return 0;

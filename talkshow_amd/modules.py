@@ -457,6 +457,12 @@ class FaceGenerator(NativeModule):
     def _destroy(self, h):
         _lib.load().ts_face_destroy(h)
 
+    def set_arith(self, bf16_products=0):
+        """OPT-IN arithmetic plan of the generator's GEMMs (`ts_face_set_arith`): 0 = fp32 MFMA (default; the parity path),
+        3 / 6 = split-bf16 with three / six exact bf16 products per fp32 product.  Returns self."""
+        _lib.check(_lib.load().ts_face_set_arith(self.handle(), int(bf16_products)))
+        return self
+
     def run(self, wav, id_vec, frames, want_hidden=False):
         """wav (B,N) device fp32, id_vec (B,num_classes) -> (B,frames,103) [, hidden (B,frames,768)]."""
         dev = self._dev()

@@ -635,6 +635,32 @@ def test_wrapper_face(hip, golden, tmp_path):
     assert w.each_dim == [3, 72, 90, 100]
 
 
+@pytest.mark.parametrize("products,tol_hidden,tol_out", [(6, 1e-4, 1e-4), (3, 1e-4, 1e-4)])
+def test_face_split_bf16_plan_vs_reference_golden(hip, golden, products, tol_hidden, tol_out):
+    """OPT-IN split-bf16 arithmetic (`ts_face_set_arith`, csrc/conv_gemm_split.hip) on the BASELINE-length reference goldens
+    (two 10 s clips, hidden state and output produced by the reference wrapper over transformers): the same 1e-4 bar as the
+    fp32 path, on both.  The fp32 plan stays the default and is untouched: switching back reproduces its bits."""
+    from talkshow_amd.modules import FaceGenerator
+    g, gf = golden("face_10s"), golden("face_full")
+    seed, B, N = (int(v) for v in g["wav_seed"])
+    wav = synth.wav16(seed, B, N)
+    m = FaceGenerator().cuda()
+    m.load_state_dict(synth.to_torch(synth.face_state_dict(seed=7)))
+    base, base_hid = m.run(wav, g["ids"], 300, want_hidden=True)
+    out, hid = m.set_arith(products).run(wav, g["ids"], 300, want_hidden=True)
+    err_o, err_h = float(np.abs(out.cpu().numpy() - g["out"]).max()), float((hid - base_hid).abs().max())
+    print(f"split-bf16 x{products}: out vs reference golden {err_o:.2e}, hidden vs fp32 path {err_h:.2e}")
+    assert err_o <= tol_out
+    assert err_h <= tol_hidden
+    # the 2 s goldens carry the reference's hidden state itself
+    frame = gf["out"].shape[1]
+    o2, h2 = m.run(gf["wav"], gf["ids"], frame, want_hidden=True)
+    np.testing.assert_allclose(h2.cpu().numpy(), gf["hidden"], atol=tol_hidden, rtol=0)
+    np.testing.assert_allclose(o2.cpu().numpy(), gf["out"], atol=tol_out, rtol=0)
+    again, _ = m.set_arith(0).run(wav, g["ids"], 300, want_hidden=True)
+    assert torch.equal(again, base)
+
+
 def test_face_one_minute_clip_vs_oracle(hip):
     """A 60 s clip in ONE call (960 000 samples -> 1 800 frames: attention rows of 1 824 entries, beyond the 512 the softmax
     kernel keeps in registers) against the CPU oracle — the reference's `infer_on_audio` takes a wav of any length
