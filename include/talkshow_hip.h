@@ -59,6 +59,10 @@ int ts_stream_create_cus(ts_ctx *ctx, int cu_first, int cu_count, void **out_str
 /* Tuning aid: with TS_SKINNY_TRACE=1 the chain kernel stamps the device wall clock (100 MHz) at five points; this reads
  * (and resets) the records, 6 uint64 each.  Returns the number of records or -1. */
 int ts_debug_skinny_trace(unsigned long long *out, int max_records);
+/* Measurement aid: launches a one-wave kernel on `stream` that, every window_us for n windows, writes three uint64 to dev_out
+ * (device memory, 3 n values): wall-clock ticks (100 MHz) since its start, ticks of this window, shader-clock cycles of this
+ * window — the clock the chip actually sustains while other streams load it (tools/conv_clock.py).  No reference counterpart. */
+int ts_debug_clock_sample(unsigned long long *dev_out, int n, int window_us, void *stream);
 /* Host-only helper (no GPU needed): the TILED copy of a row-major weight matrix W[N][ldw] (K columns used) that the
  * PixelCNN chain kernel multiplies with — every 16-column x 16-k operand fragment one contiguous KB in lane order
  * (DESIGN.md §3/§4); epi 0 = linear column order, 1 = gate (8 tanh channels + their 8 sigmoid partners per tile,

@@ -60,6 +60,12 @@ int ts_debug_skinny_trace(unsigned long long *out, int max_records) {
     if (!out) return -1;
     return ts::skinny_trace_read(out, max_records);
 }
+// measurement aid: a one-wave kernel on `stream` that records the shader clock the chip runs at, every window_us, n times
+int ts_debug_clock_sample(unsigned long long *dev_out, int n, int window_us, void *stream) {
+    if (!dev_out || n < 1 || window_us < 1) return fail("ts_debug_clock_sample: bad argument");
+    TS_HIP(ts::launch_clock_sample(dev_out, n, (unsigned long long)window_us * 100, (hipStream_t)stream));
+    return 0;
+}
 int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int gateD, float *out) {
     if (!W || !out || N < 1 || K < 16 || K % 16 || ldw < K) return fail("ts_debug_tile_weights: bad argument");
     if (epi == ts::EPI_GATE && (gateD < 8 || gateD % 8 || N % (2 * gateD))) return fail("ts_debug_tile_weights: gate tiles need gateD % 8 == 0 and N % (2 gateD) == 0");

@@ -29,8 +29,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;   // LDS-qualified: volatile accesses must not fall back to flat
 
+// one BM x BN output tile at (m0, n0) of problem / group `zidx`; smem: 2 * (BM + BN) * (BK + 4) floats of LDS
 template <int BM, int BN, int WM, int WN, int BK = 32>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv_tile(const ConvParams &p, const int zidx, const int m0, const int n0, float *smem) {
     constexpr int LDS_LD = BK + 4;   // 36 (68) floats: conflict-free row pitch for ds_read_b128
     constexpr int KC = BK / 32;      // 32-float column blocks per chunk
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -38,14 +39,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     constexpr int PA = BM / 32, PB = BN / 32;   // 32-row load passes per operand
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
 
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_LD];
+    float (*As)[BM][LDS_LD] = reinterpret_cast<float (*)[BM][LDS_LD]>(smem);
+    float (*Bs)[BN][LDS_LD] = reinterpret_cast<float (*)[BN][LDS_LD]>(smem + 2 * BM * LDS_LD);
 
-    const ConvGroup &g = p.g[p.zdiv > 0 ? 0 : blockIdx.z];
+    const ConvGroup &g = p.g[p.zdiv > 0 ? 0 : zidx];
     const float *gx = g.x, *gw = g.w, *gbias = g.bias, *gres = g.res;
     float *gout = g.out;
     if (p.zdiv > 0) {   // batched problems: shift every pointer by this problem's offsets
-        const int z0 = blockIdx.z / p.zdiv, z1 = blockIdx.z - z0 * p.zdiv;
+        const int z0 = zidx / p.zdiv, z1 = zidx - z0 * p.zdiv;
         gx += z0 * p.x_zs0 + z1 * p.x_zs1;
         gw += z0 * p.w_zs0 + z1 * p.w_zs1;
         gout += z0 * p.o_zs0 + z1 * p.o_zs1;
@@ -57,7 +58,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
     // ---- per-thread global-load geometry: row (tid/8) of each 32-row pass, float4 column (tid%8) ----
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
@@ -184,6 +184,31 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][e], fb[slot][j][e], acc[i][j], 0, 0, 0);
     };
+    // ---- the same pieces one at a time, for the hand-ordered steady state below ----
+    constexpr int MF = TM * TN * 4;          // MFMAs of one group of 8 k
+    constexpr int NR = (PA + PB) * KC;       // staging registers (16 B per thread each)
+    constexpr int NF = TM + TN;              // fragments of a group
+    auto mfma_one = [&](int slot, int k) {   // k-th MFMA of a group, in mfma_q's order
+        const int e = k / (TM * TN), ij = k % (TM * TN), i = ij / TN, j = ij % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][e], fb[slot][j][e], acc[i][j], 0, 0, 0);
+    };
+    auto read_one = [&](int buf, int q, int slot, int f) {
+        if (f < TM)
+            fa[slot][f] = *(const volatile lds_f32x4 *)__builtin_assume_aligned(&As[buf][wm * WM + f * 32 + li][q * 8 + lh * 4], 16);
+        else
+            fb[slot][f - TM] = *(const volatile lds_f32x4 *)__builtin_assume_aligned(&Bs[buf][wn * WN + (f - TM) * 32 + li][q * 8 + lh * 4], 16);
+    };
+    auto move_one = [&](int buf, int r) {    // staging register r: its chunk to LDS, then refilled with the chunk after
+        if (r < PA * KC) {
+            const int i = r / KC, c = r % KC;
+            *reinterpret_cast<f32x4 *>(&As[buf][i * 32 + lrow][lc4 + c * 32]) = ra[i][c];
+            ra[i][c] = *reinterpret_cast<const f32x4 *>(pa[i] + c * 32);
+        } else {
+            const int i = (r - PA * KC) / KC, c = (r - PA * KC) % KC;
+            *reinterpret_cast<f32x4 *>(&Bs[buf][i * 32 + lrow][lc4 + c * 32]) = rb[i][c];
+            rb[i][c] = *reinterpret_cast<const f32x4 *>(pb[i] + c * 32);
+        }
+    };
     const int nchunks = p.Ktot / BK;
     load_chunk();
     store_chunk(0);
@@ -195,6 +220,59 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     read_frags(0, 0, 0);
     int buf = 0;
     int it = 0;
+#ifndef TS_CONV_OLD_LOOP
+    // Steady state, hand ordered (sched_barrier after every step): chunk it+1 -> LDS, chunk it+2 -> registers, MFMAs of chunk it.
+    // The matrix pipe gives an older wave priority over a younger one, so the second workgroup of a CU only runs in the first
+    // one's gaps, and its four waves (one per SIMD) are tied together by their barrier: a wave's own instruction stream has
+    // to keep the pipe fed.  Hence at most one or two side operations behind each MFMA (64 cycles of pipe): the LDS write and
+    // global refill of one staging register, or one fragment read; never a run of them with a single MFMA in flight.
+    for (; it + 2 < nchunks; ++it) {
+        advance();
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int OPS0 = NR + NF, PER0 = (OPS0 + MF - 1) / MF;
+#pragma unroll
+        for (int k = 0; k < MF; ++k) {       // group 0: staging traffic + the fragments of group 1
+            mfma_one(0, k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int o = k * PER0; o < (k + 1) * PER0 && o < OPS0; ++o) {
+                if (o < NR) move_one(buf ^ 1, o);
+                else read_one(buf, 1, 1, o - NR);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 1; q + 1 < NQ; ++q) {   // middle groups: the fragments of the next group
+#pragma unroll
+            for (int k = 0; k < MF; ++k) {
+                mfma_one(q & 1, k);
+                if (k < NF) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_one(buf, q + 1, (q + 1) & 1, k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        {                                    // last group: barrier half way, then group 0's fragments of the next chunk
+            constexpr int H = (MF - NF) < MF / 2 ? (MF - NF) : MF / 2;
+#pragma unroll
+            for (int k = 0; k < H; ++k) mfma_one((NQ - 1) & 1, k);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = H; k < MF; ++k) {
+                mfma_one((NQ - 1) & 1, k);
+                if (k - H < NF) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_one(buf ^ 1, 0, 0, k - H);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+#else
     for (; it + 2 < nchunks; ++it) {   // steady state: chunk it+1 -> LDS, chunk it+2 -> registers, MFMAs of chunk it
         advance();
         store_chunk(buf ^ 1);
@@ -207,13 +285,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                 __syncthreads();
                 read_frags(buf ^ 1, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
             mfma_q(q & 1);
-            // the LDS writes and the global loads of this iteration must be issued within the first MFMA group: left to
-            // itself the scheduler sinks the loads to the end of the iteration and the next one stalls on them
             if (q == 0) __builtin_amdgcn_sched_barrier(0);
         }
         buf ^= 1;
     }
+#endif
     for (; it < nchunks; ++it) {       // last two chunks: nothing left to load
         const bool has_next = it + 1 < nchunks;
         if (has_next) store_chunk(buf ^ 1);
@@ -265,6 +343,47 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
 }
 
+template <int BM, int BN, int WM, int WN, int BK = 32>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * (BK + 4)];
+    conv_tile<BM, BN, WM, WN, BK>(p, blockIdx.z, blockIdx.x * BM, blockIdx.y * BN, smem);
+}
+
+// Banded launch: the rows of the output are cut into up to four bands, each tiled with its own shape — 128 x 128 where whole
+// rounds of 512 resident workgroups fit, the small shape S for what is left, so that the last round of a layer is made of
+// short tiles (2 400 tiles of 128 x 128 are 4.69 rounds: the fifth is 69 % full and lasts as long as the others), and
+// optionally one early band of small tiles that puts the two workgroups of a CU half a tile out of phase (one's prologue /
+// epilogue under the other's main loop).  Workgroup ids run band by band; inside a band M tiles fastest, then N, then group.
+template <int SBM, int SBN, int SWM, int SWN>
+__global__ __launch_bounds__(256) void conv_gemm_banded_kernel(const ConvParams p, const ConvBands bands) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (128 + 128) * 36];
+    const int id = blockIdx.x;
+    int b = 0;
+    while (b + 1 < bands.nb && id >= bands.first[b + 1]) ++b;
+    int local = id - bands.first[b];
+    const int mt = bands.mt[b], big = bands.big[b];
+    const int nt = big ? (p.N + 127) / 128 : (p.N + SBN - 1) / SBN;
+    int z, m, n;
+    if (bands.xcd) {
+        // workgroup id % 8 = XCD (1-D grid): each XCD takes a contiguous eighth of the band's tile list, N tiles fastest, so the
+        // 64 workgroups resident on an XCD are (64 / nt) row blocks x all nt column tiles and share both operands in its L2
+        const int per = (bands.first[b + 1] - bands.first[b]) >> 3;   // band id ranges are padded to multiples of 8
+        local = (local & 7) * per + (local >> 3);
+        if (local >= mt * nt * p.ngroups) return;
+        const int r = local / nt;
+        n = local - r * nt;
+        z = r / mt;
+        m = r - z * mt;
+    } else {
+        const int rest = local / mt;
+        m = local - rest * mt;
+        z = rest / nt;
+        n = rest - z * nt;
+    }
+    if (big) conv_tile<128, 128, 64, 64>(p, z, bands.row0[b] + m * 128, n * 128, smem);
+    else conv_tile<SBM, SBN, SWM, SWN>(p, z, bands.row0[b] + m * SBM, n * SBN, smem);
+}
+
 double conv_gemm_flops(const ConvParams &p) { return 2.0 * p.M * (double)p.N * p.Ktot * p.ngroups; }
 
 
@@ -288,17 +407,73 @@ static int pick_tile(const ConvParams &p) {
     return best;
 }
 
+// Bands for a layer that the cost model gives to 128 x 128 tiles.  small = 2 (64 x 64), 3 (128 x 64), 4 (64 x 128).
+// mode 1: big tiles for as many whole rounds of `slots` resident workgroups as fit, small tiles for the rest;
+// mode 2: the same, with the second half-round (workgroups slots/2 .. slots) made of small tiles.
+static bool plan_bands(const ConvParams &p, int mode, int small, ConvBands &bd) {
+    const int slots = 512;
+    const int sbm = (small == 3) ? 128 : 64, sbn = (small == 4) ? 128 : 64;
+    const int MT = (p.M + 127) / 128, NT = ((p.N + 127) / 128) * p.ngroups, NTS = ((p.N + sbn - 1) / sbn) * p.ngroups;
+    const long total = (long)MT * NT;
+    const int rounds = (int)(total / slots);
+    if (mode <= 0 || p.zdiv > 0 || rounds < 1 || total % slots == 0) return false;
+    int mb = (int)((long)rounds * slots / NT);   // M tiles of 128 rows given to the full rounds
+    if (mb >= MT) return false;
+    bd = ConvBands{};
+    static const int xcd = getenv("TS_CONV_XCD") ? atoi(getenv("TS_CONV_XCD")) : 0;
+    bd.xcd = xcd;
+    int nb = 0, id = 0, row = 0;
+    auto band = [&](int big, int rows) {   // rows: multiple of the band's tile height, or up to the end of the matrix
+        const int h = big ? 128 : sbm, mt = (rows + h - 1) / h;
+        if (mt <= 0) return;
+        bd.first[nb] = id; bd.row0[nb] = row; bd.mt[nb] = mt; bd.big[nb] = big;
+        id += mt * (big ? NT : NTS);
+        if (bd.xcd) id = (id + 7) & ~7;   // each band starts on XCD 0 and holds whole groups of 8 ids
+        row += mt * h;
+        ++nb;
+    };
+    if (mode == 2 && rounds >= 2) {
+        const int m0 = (slots / 2 + NT - 1) / NT;                       // big M tiles of the first half round
+        const int m1 = ((slots / 2 + NTS - 1) / NTS * sbm + 127) / 128;   // 128-row blocks of the small half round
+        if (m0 + m1 < mb) {
+            band(1, m0 * 128);
+            band(0, m1 * 128);
+            band(1, (mb - m0 - m1) * 128);
+        } else {
+            band(1, mb * 128);
+        }
+    } else {
+        band(1, mb * 128);
+    }
+    band(0, p.M - row);
+    bd.nb = nb;
+    bd.first[nb] = id;
+    return true;
+}
+
 hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream) {
     ConvParams p = p_in;
     if (!p.zero) {
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) p.zero = skinny_zero_buffer(dev);
     }
-    if (tile == 0) tile = pick_tile(p);
     dim3 block(256);
     auto grid = [&](int bm, int bn) { return dim3((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, p.ngroups); };
     // zero buffer (ts::skinny_init, called by ts_ctx_create): 64 Ki floats; parked pointers walk at most Ktot floats of it
     if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000) return hipErrorInvalidValue;
+    if (tile == 0 && pick_tile(p) == 1) {
+        static const int mix = getenv("TS_CONV_MIX") ? atoi(getenv("TS_CONV_MIX")) : 1;
+        static const int small = getenv("TS_CONV_TAIL") ? atoi(getenv("TS_CONV_TAIL")) : 2;
+        ConvBands bd;
+        if (plan_bands(p, mix, small, bd)) {
+            const dim3 g1(bd.first[bd.nb]);
+            if (small == 3) hipLaunchKernelGGL((conv_gemm_banded_kernel<128, 64, 64, 32>), g1, block, 0, stream, p, bd);
+            else if (small == 4) hipLaunchKernelGGL((conv_gemm_banded_kernel<64, 128, 32, 64>), g1, block, 0, stream, p, bd);
+            else hipLaunchKernelGGL((conv_gemm_banded_kernel<64, 64, 32, 32>), g1, block, 0, stream, p, bd);
+            return hipGetLastError();
+        }
+    }
+    if (tile == 0) tile = pick_tile(p);
     switch (tile) {
         case 1: hipLaunchKernelGGL((conv_gemm_kernel<128, 128, 64, 64>), grid(128, 128), block, 0, stream, p); break;
         case 2: hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 32, 32>), grid(64, 64), block, 0, stream, p); break;

@@ -50,6 +50,14 @@ struct ConvParams {
     long x_zs0, x_zs1, w_zs0, w_zs1, o_zs0, o_zs1, b_zs1, r_zs0, r_zs1;
 };
 
+// row bands of a banded conv_gemm launch (conv_gemm.hip): band b covers rows [row0, row0 + mt * tile height) with 128 x 128 tiles
+// (big) or the launch's small shape; workgroup ids [first[b], first[b + 1])
+struct ConvBands {
+    int nb, xcd;
+    int first[5];
+    int row0[4], mt[4], big[4];
+};
+
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 (BK 64), 6 = 160x128, 7 = 96x128 (for tuning / tests)
 hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream);
 // the same convolution on the bf16 matrix cores with fp32 operands split into `planes` bf16 terms (2: three products, ~2^-16;
@@ -154,6 +162,8 @@ hipError_t launch_assemble_full(const float *body, const float *face, const floa
                                 float *out, hipStream_t stream);
 // int64 -> int32 (labels, teacher-forced codes)
 hipError_t launch_i64_to_i32(const int64_t *src, int *dst, long n, hipStream_t stream);
+// measurement aid: n records of (wall ticks since start, wall ticks of the window, shader cycles of the window), 100 MHz wall clock
+hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long long window_ticks, hipStream_t stream);
 
 struct SampleParams {
     const float *logits;   // [B][V]

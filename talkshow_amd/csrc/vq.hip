@@ -219,6 +219,31 @@ hipError_t launch_i64_to_i32(const int64_t *src, int *dst, long n, hipStream_t s
     return hipGetLastError();
 }
 
+// measurement aid: one wave that sleeps and, every `window_ticks` of the 100 MHz wall clock, records (wall ticks, shader cycles)
+// since the previous record — the shader clock the chip actually runs at while other streams load it
+__global__ void clock_sample_kernel(unsigned long long *out, int n, unsigned long long window_ticks) {
+    if (threadIdx.x != 0) return;
+    unsigned long long w0 = wall_clock64(), c0 = clock64();
+    const unsigned long long wstart = w0;
+    for (int i = 0; i < n; ++i) {
+        unsigned long long w1;
+        do {
+            __builtin_amdgcn_s_sleep(64);
+            w1 = wall_clock64();
+        } while (w1 - w0 < window_ticks);
+        const unsigned long long c1 = clock64();
+        out[3 * i] = w1 - wstart;
+        out[3 * i + 1] = w1 - w0;
+        out[3 * i + 2] = c1 - c0;
+        w0 = w1;
+        c0 = c1;
+    }
+}
+hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long long window_ticks, hipStream_t stream) {
+    hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(64), 0, stream, out, n, window_ticks);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // sampler: one workgroup per clip over V logits.
 //   greedy   : argmax, ties -> lowest index (torch.argmax on CPU returns the first maximum).
