@@ -220,7 +220,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const int zidx, c
     read_frags(0, 0, 0);
     int buf = 0;
     int it = 0;
-#ifndef TS_CONV_OLD_LOOP
     // Steady state, hand ordered (sched_barrier after every step): chunk it+1 -> LDS, chunk it+2 -> registers, MFMAs of chunk it.
     // The matrix pipe gives an older wave priority over a younger one, so the second workgroup of a CU only runs in the first
     // one's gaps, and its four waves (one per SIMD) are tied together by their barrier: a wave's own instruction stream has
@@ -272,26 +271,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const int zidx, c
         }
         buf ^= 1;
     }
-#else
-    for (; it + 2 < nchunks; ++it) {   // steady state: chunk it+1 -> LDS, chunk it+2 -> registers, MFMAs of chunk it
-        advance();
-        store_chunk(buf ^ 1);
-        load_chunk();
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (q + 1 < NQ) {
-                read_frags(buf, q + 1, (q + 1) & 1);
-            } else {
-                __syncthreads();
-                read_frags(buf ^ 1, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_q(q & 1);
-            if (q == 0) __builtin_amdgcn_sched_barrier(0);
-        }
-        buf ^= 1;
-    }
-#endif
     for (; it < nchunks; ++it) {       // last two chunks: nothing left to load
         const bool has_next = it + 1 < nchunks;
         if (has_next) store_chunk(buf ^ 1);
@@ -349,39 +328,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     conv_tile<BM, BN, WM, WN, BK>(p, blockIdx.z, blockIdx.x * BM, blockIdx.y * BN, smem);
 }
 
-// Banded launch: the rows of the output are cut into up to four bands, each tiled with its own shape — 128 x 128 where whole
-// rounds of 512 resident workgroups fit, the small shape S for what is left, so that the last round of a layer is made of
-// short tiles (2 400 tiles of 128 x 128 are 4.69 rounds: the fifth is 69 % full and lasts as long as the others), and
-// optionally one early band of small tiles that puts the two workgroups of a CU half a tile out of phase (one's prologue /
-// epilogue under the other's main loop).  Workgroup ids run band by band; inside a band M tiles fastest, then N, then group.
+// Banded launch: the rows of the output are cut into two bands — 128 x 128 tiles where whole rounds of 512 resident workgroups
+// fit, the small shape S for what is left, so that the last, partly filled round of a layer is made of short tiles (2 400 tiles
+// of 128 x 128 are 4.69 rounds).  Workgroup ids run band by band; inside a band M tiles fastest, then N, then group.
 template <int SBM, int SBN, int SWM, int SWN>
 __global__ __launch_bounds__(256) void conv_gemm_banded_kernel(const ConvParams p, const ConvBands bands) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (128 + 128) * 36];
-    const int id = blockIdx.x;
-    int b = 0;
-    while (b + 1 < bands.nb && id >= bands.first[b + 1]) ++b;
-    int local = id - bands.first[b];
-    const int mt = bands.mt[b], big = bands.big[b];
+    const int big = (int)blockIdx.x < bands.first_small;
+    const int local = big ? blockIdx.x : blockIdx.x - bands.first_small;
+    const int mt = big ? bands.mt_big : bands.mt_small;
     const int nt = big ? (p.N + 127) / 128 : (p.N + SBN - 1) / SBN;
-    int z, m, n;
-    if (bands.xcd) {
-        // workgroup id % 8 = XCD (1-D grid): each XCD takes a contiguous eighth of the band's tile list, N tiles fastest, so the
-        // 64 workgroups resident on an XCD are (64 / nt) row blocks x all nt column tiles and share both operands in its L2
-        const int per = (bands.first[b + 1] - bands.first[b]) >> 3;   // band id ranges are padded to multiples of 8
-        local = (local & 7) * per + (local >> 3);
-        if (local >= mt * nt * p.ngroups) return;
-        const int r = local / nt;
-        n = local - r * nt;
-        z = r / mt;
-        m = r - z * mt;
-    } else {
-        const int rest = local / mt;
-        m = local - rest * mt;
-        z = rest / nt;
-        n = rest - z * nt;
-    }
-    if (big) conv_tile<128, 128, 64, 64>(p, z, bands.row0[b] + m * 128, n * 128, smem);
-    else conv_tile<SBM, SBN, SWM, SWN>(p, z, bands.row0[b] + m * SBM, n * SBN, smem);
+    const int rest = local / mt, m = local - rest * mt;
+    const int z = rest / nt, n = rest - z * nt;
+    if (big) conv_tile<128, 128, 64, 64>(p, z, m * 128, n * 128, smem);
+    else conv_tile<SBM, SBN, SWM, SWN>(p, z, bands.mt_big * 128 + m * SBM, n * SBN, smem);
 }
 
 double conv_gemm_flops(const ConvParams &p) { return 2.0 * p.M * (double)p.N * p.Ktot * p.ngroups; }
@@ -407,47 +367,20 @@ static int pick_tile(const ConvParams &p) {
     return best;
 }
 
-// Bands for a layer that the cost model gives to 128 x 128 tiles.  small = 2 (64 x 64), 3 (128 x 64), 4 (64 x 128).
-// mode 1: big tiles for as many whole rounds of `slots` resident workgroups as fit, small tiles for the rest;
-// mode 2: the same, with the second half-round (workgroups slots/2 .. slots) made of small tiles.
-static bool plan_bands(const ConvParams &p, int mode, int small, ConvBands &bd) {
+// Bands for a layer that the cost model gives to 128 x 128 tiles: big tiles for as many whole rounds of 512 resident workgroups
+// as fit, 64 x 128 tiles for the rows that are left (measured against 64 x 64 and 128 x 64: tools/conv_mix_ab.sh).
+static bool plan_bands(const ConvParams &p, ConvBands &bd) {
     const int slots = 512;
-    const int sbm = (small == 3) ? 128 : 64, sbn = (small == 4) ? 128 : 64;
-    const int MT = (p.M + 127) / 128, NT = ((p.N + 127) / 128) * p.ngroups, NTS = ((p.N + sbn - 1) / sbn) * p.ngroups;
+    const int MT = (p.M + 127) / 128, NT = ((p.N + 127) / 128) * p.ngroups;
     const long total = (long)MT * NT;
     const int rounds = (int)(total / slots);
-    if (mode <= 0 || p.zdiv > 0 || rounds < 1 || total % slots == 0) return false;
-    int mb = (int)((long)rounds * slots / NT);   // M tiles of 128 rows given to the full rounds
+    if (p.zdiv > 0 || rounds < 1 || total % slots == 0) return false;
+    const int mb = (int)((long)rounds * slots / NT);   // M tiles of 128 rows given to the full rounds
     if (mb >= MT) return false;
-    bd = ConvBands{};
-    static const int xcd = getenv("TS_CONV_XCD") ? atoi(getenv("TS_CONV_XCD")) : 0;
-    bd.xcd = xcd;
-    int nb = 0, id = 0, row = 0;
-    auto band = [&](int big, int rows) {   // rows: multiple of the band's tile height, or up to the end of the matrix
-        const int h = big ? 128 : sbm, mt = (rows + h - 1) / h;
-        if (mt <= 0) return;
-        bd.first[nb] = id; bd.row0[nb] = row; bd.mt[nb] = mt; bd.big[nb] = big;
-        id += mt * (big ? NT : NTS);
-        if (bd.xcd) id = (id + 7) & ~7;   // each band starts on XCD 0 and holds whole groups of 8 ids
-        row += mt * h;
-        ++nb;
-    };
-    if (mode == 2 && rounds >= 2) {
-        const int m0 = (slots / 2 + NT - 1) / NT;                       // big M tiles of the first half round
-        const int m1 = ((slots / 2 + NTS - 1) / NTS * sbm + 127) / 128;   // 128-row blocks of the small half round
-        if (m0 + m1 < mb) {
-            band(1, m0 * 128);
-            band(0, m1 * 128);
-            band(1, (mb - m0 - m1) * 128);
-        } else {
-            band(1, mb * 128);
-        }
-    } else {
-        band(1, mb * 128);
-    }
-    band(0, p.M - row);
-    bd.nb = nb;
-    bd.first[nb] = id;
+    bd.mt_big = mb;
+    bd.first_small = mb * NT;
+    bd.mt_small = (p.M - mb * 128 + 63) / 64;
+    bd.total = bd.first_small + bd.mt_small * NT;      // 64 x 128 tiles: as many column tiles as the big ones
     return true;
 }
 
@@ -462,14 +395,10 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
     // zero buffer (ts::skinny_init, called by ts_ctx_create): 64 Ki floats; parked pointers walk at most Ktot floats of it
     if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000) return hipErrorInvalidValue;
     if (tile == 0 && pick_tile(p) == 1) {
-        static const int mix = getenv("TS_CONV_MIX") ? atoi(getenv("TS_CONV_MIX")) : 1;
-        static const int small = getenv("TS_CONV_TAIL") ? atoi(getenv("TS_CONV_TAIL")) : 2;
+        static const bool banded = !(getenv("TS_CONV_BANDS") && atoi(getenv("TS_CONV_BANDS")) == 0);   // 0: plain grid (A/B, tests)
         ConvBands bd;
-        if (plan_bands(p, mix, small, bd)) {
-            const dim3 g1(bd.first[bd.nb]);
-            if (small == 3) hipLaunchKernelGGL((conv_gemm_banded_kernel<128, 64, 64, 32>), g1, block, 0, stream, p, bd);
-            else if (small == 4) hipLaunchKernelGGL((conv_gemm_banded_kernel<64, 128, 32, 64>), g1, block, 0, stream, p, bd);
-            else hipLaunchKernelGGL((conv_gemm_banded_kernel<64, 64, 32, 32>), g1, block, 0, stream, p, bd);
+        if (banded && plan_bands(p, bd)) {
+            hipLaunchKernelGGL((conv_gemm_banded_kernel<64, 128, 32, 64>), dim3(bd.total), block, 0, stream, p, bd);
             return hipGetLastError();
         }
     }

@@ -50,12 +50,10 @@ struct ConvParams {
     long x_zs0, x_zs1, w_zs0, w_zs1, o_zs0, o_zs1, b_zs1, r_zs0, r_zs1;
 };
 
-// row bands of a banded conv_gemm launch (conv_gemm.hip): band b covers rows [row0, row0 + mt * tile height) with 128 x 128 tiles
-// (big) or the launch's small shape; workgroup ids [first[b], first[b + 1])
+// banded conv_gemm launch (conv_gemm.hip): rows [0, mt_big * 128) in 128 x 128 tiles = workgroups [0, first_small), the rows
+// after them in mt_small row blocks of the small tile shape = workgroups [first_small, total)
 struct ConvBands {
-    int nb, xcd;
-    int first[5];
-    int row0[4], mt[4], big[4];
+    int mt_big, mt_small, first_small, total;
 };
 
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 (BK 64), 6 = 160x128, 7 = 96x128 (for tuning / tests)

@@ -94,6 +94,37 @@ def test_conv_tile_shapes_agree(hip):
         assert np.array_equal(o, outs[2]), f"tile {tile} differs from the 64x64 tile"
 
 
+def test_conv_banded_launch_matches_plain_tiles(hip):
+    """Layers of more than one round of 512 workgroups are launched in two bands (128 x 128 tiles for the whole rounds, 64 x 128
+    for the rows that are left: conv_gemm.hip `plan_bands`).  Every tile shape walks K in the same order, so the banded launch
+    (tile 0 = auto) must be bit-identical to the plain 128 x 128 and 64 x 64 grids; M = 19 227 is ragged against both heights
+    and N = 500 against the tile width (600 big tiles = one round of 512 = 128 row blocks, 23 row blocks left)."""
+    _lib, lib, ctx = hip
+    rng = np.random.default_rng(78)
+    B, L, Cin, Cout, K = 3, 6409, 64, 500, 3
+    x = rng.standard_normal((B, L, Cin)).astype(np.float32)
+    npad = (Cout + 127) // 128 * 128
+    w = np.zeros((npad, K * Cin), np.float32)
+    w[:Cout] = rng.standard_normal((Cout, K * Cin)).astype(np.float32) / np.sqrt(K * Cin)
+    b = np.zeros(npad, np.float32)
+    b[:Cout] = rng.standard_normal(Cout).astype(np.float32)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    outs = {}
+    for tile in (0, 1, 2):
+        out = torch.full((B, L, Cout), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, tile, 1,
+                                          _lib.dptr(out), None, None))
+        torch.cuda.synchronize()
+        outs[tile] = out.cpu().numpy()
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    rows = rng.integers(0, L, 64)
+    xp = np.pad(x, ((0, 0), (1, 1), (0, 0)))
+    ref = sum(xp[:, rows + k, :] @ w[:Cout, k * Cin:(k + 1) * Cin].T for k in range(K)) + b[:Cout]
+    ref = np.where(ref >= 0, ref, 0.2 * ref).astype(np.float32)
+    np.testing.assert_allclose(outs[0][:, rows, :], ref, atol=2e-5, rtol=1e-5)
+
+
 def _fma32(a, b, c):
     """float32 fma emulated through float64 (the product is exact there; the second rounding differs from a true fma only in
     ~2^-29 of the cases)."""
