@@ -63,6 +63,9 @@ int ts_debug_skinny_trace(unsigned long long *out, int max_records);
  * (device memory, 3 n values): wall-clock ticks (100 MHz) since its start, ticks of this window, shader-clock cycles of this
  * window — the clock the chip actually sustains while other streams load it (tools/conv_clock.py).  No reference counterpart. */
 int ts_debug_clock_sample(unsigned long long *dev_out, int n, int window_us, void *stream);
+/* Tuning aid: with TS_CHAIN_TRACE=1 one workgroup of the persistent chain kernel stamps the device wall clock (100 MHz) six times per
+ * stage; this copies the last launch's records, 8 uint64 per stage (tools/persist_trace.py).  Returns the number of stages or -1. */
+int ts_debug_chain_trace(unsigned long long *out, int max_stages);
 /* Host-only helper (no GPU needed): the TILED copy of a row-major weight matrix W[N][ldw] (K columns used) that the
  * PixelCNN chain kernel multiplies with — every 16-column x 16-k operand fragment one contiguous KB in lane order
  * (DESIGN.md §3/§4); epi 0 = linear column order, 1 = gate (8 tanh channels + their 8 sigmoid partners per tile,

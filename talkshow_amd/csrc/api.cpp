@@ -1,6 +1,7 @@
 // Whole-wrapper entry points and the single-operator entry points used by the kernel-level parity tests.
 #include <vector>
 #include "host_common.h"
+#include "skinny_desc.h"
 
 using namespace ts;
 
@@ -66,6 +67,8 @@ int ts_debug_clock_sample(unsigned long long *dev_out, int n, int window_us, voi
     TS_HIP(ts::launch_clock_sample(dev_out, n, (unsigned long long)window_us * 100, (hipStream_t)stream));
     return 0;
 }
+// tuning aid (TS_CHAIN_TRACE=1): per-stage wall-clock stamps of the persistent chain kernel's last launch, 8 uint64 per stage
+int ts_debug_chain_trace(unsigned long long *out, int max_stages) { return ts::chain_trace_read(out, max_stages); }
 int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int gateD, float *out) {
     if (!W || !out || N < 1 || K < 16 || K % 16 || ldw < K) return fail("ts_debug_tile_weights: bad argument");
     if (epi == ts::EPI_GATE && (gateD < 8 || gateD % 8 || N % (2 * gateD))) return fail("ts_debug_tile_weights: gate tiles need gateD % 8 == 0 and N % (2 gateD) == 0");

@@ -753,6 +753,8 @@ static int skinny_grid(SkinnyParams &p, int ncol) {
     return 0;
 }
 
+bool skinny_descriptor_kernel_enabled();
+
 hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t stream) {
     if (n < 1 || n > SKINNY_MAX_PROBLEMS) return hipErrorInvalidValue;
     SkinnyBatch b;
@@ -771,6 +773,34 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
         gx = gx > b.p[i].grid_x ? gx : b.p[i].grid_x;
         gy = gy > b.p[i].grid_y ? gy : b.p[i].grid_y;
         Q = Q > b.p[i].Ktot / 8 ? Q : b.p[i].Ktot / 8;
+    }
+    if (ChainRecorder *rec = chain_recorder()) {   // a pass is being recorded for the persistent chain kernel: describe, do not launch
+        int dev = 0;
+        const int W16 = Q >= 32 ? 8 : 4;
+        ChainStage stg;
+        std::memset(&stg, 0, sizeof(stg));
+        stg.kind = 0;
+        stg.W = W16;
+        bool ok = ncol == 16 && skinny_descriptor_kernel_enabled() && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_zero[dev];
+        int total = 0;
+        for (int i = 0; i < 8; ++i) stg.start[i] = 0x7fffffff;
+        for (int i = 0; i < n && ok; ++i) {
+            const int cnt = b.p[i].Ktot / (16 * W16);
+            // rows are clips, or (clip, column) pairs clip-major (M = 2 x clips): an XCD's clips are then two row tiles
+            const int mult = b.p[i].M / rec->M;
+            ok = b.p[i].M % rec->M == 0 && (mult == 1 || mult == 2) && b.p[i].grid_x % 2 == 0 && (cnt <= 4 || rec->M == 128) &&
+                 skinny_pack_desc(b.p[i], W16, g_zero[dev], stg.d[i]);
+            stg.start[i] = total;
+            total += (b.p[i].grid_x / 2) * mult;
+        }
+        stg.ntiles = total;
+        if (!ok && rec->ok && getenv("TS_CHAIN_PERSIST_DEBUG"))
+            for (int i = 0; i < n; ++i)
+                fprintf(stderr, "[ts] persistent chain: stage %zu problem %d/%d does not fit: M=%d N=%d K=%d grid_x=%d W=%d ncol=%d\n",
+                        rec->stages.size(), i, n, b.p[i].M, b.p[i].N, b.p[i].Ktot, b.p[i].grid_x, W16, ncol);
+        if (ok) rec->stages.push_back(stg);
+        else rec->ok = false;
+        return hipSuccess;
     }
     dim3 grid(gx, gy, n);
     // K is split over the waves of the workgroup; more waves = more loads in flight (lower latency for ONE chain) but a

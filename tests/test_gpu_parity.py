@@ -860,15 +860,16 @@ def test_wav_in_code_stability(hip, tmp_path):
                                  {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"},
                                  {"TS_SKINNY_TILED": "0", "TS_WITH_CLIPS": "1"}, {"TS_PIX_DEFER_P": "0", "TS_WITH_CLIPS": "1"},
                                  {"TS_PIX_DEFER_P": "1", "TS_WITH_CLIPS": "1"}, {"TS_SKINNY_WIDE_MIN": "0", "TS_WITH_CLIPS": "1"},
-                                 {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}],
+                                 {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}, {"TS_CHAIN_PERSIST": "1", "TS_WITH_CLIPS": "1"}],
                          ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
                               "row_major_operands", "projections_in_column0", "projections_in_column1",
-                              "split_k_kernels_only", "wide_kernel_everywhere"])
+                              "split_k_kernels_only", "wide_kernel_everywhere", "persistent_chain_kernel"])
 def test_alternate_kernel_paths(hip, env):
     """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
     launches, the 32-column kernel), row-major instead of tiled operands, two placements of the next-row projections, and
     the 64 x 64 wide kernel that coalesced passes use for launches of >= 160 workgroups (forced off / forced onto every
-    launch of >= 64 clips here, small head / column-1 launches included).  The knobs are read once per process, so the
+    launch of >= 64 clips here, small head / column-1 launches included), and the opt-in persistent kernel that runs the whole
+    chain of a 128- / 256-clip pass as one launch with XCD-local barriers (skinny_persist.hip).  The knobs are read once per process, so the
     golden-vector tests are re-run in a child process with each path forced: all must stay bit-exact on the codes."""
     import subprocess
     import sys
