@@ -189,8 +189,8 @@ struct TileOps {
     int dw, tile, mt;                // the problem's descriptor word of this lane, column tile, row tile
 };
 
-template <int RB>
-__global__ __launch_bounds__(512) void chain_persist_kernel(const ChainStage *__restrict__ stages, const int nstages, ChainSync *sync, unsigned long long *trace) {
+template <int RB, bool PIPE>
+__global__ __launch_bounds__(512, PIPE ? 2 : 3) void chain_persist_kernel(const ChainStage *__restrict__ stages, const int nstages, ChainSync *sync, unsigned long long *trace) {
     constexpr int CB = 2, ROWS = RB * 16, NBLK = RB * CB, NREG = NBLK * 4, EMAX = RB * CB;   // EMAX = NREG / 4 (a W = 4 stage)
     __shared__ float red_raw[8 * NREG * 64];
     __shared__ float sf[256 + 1];
@@ -434,8 +434,10 @@ __global__ __launch_bounds__(512) void chain_persist_kernel(const ChainStage *__
     StageRegs s0, s1, s2;
     fetch_stage(0, s0);
     fetch_stage(1, s1);
+    // PIPE: the next tile's operands are issued before the current tile is finished, and a stage's first weights before the barrier
+    // in front of it (two operand sets: 240 VGPRs).  Without it the kernel needs 125 and leaves room on the CU for a conv_gemm workgroup.
     TileOps<RB, CB> cur, nxt;
-    if (H(s0, 0) == 0 && slot < H(s0, 2)) {
+    if (PIPE && H(s0, 0) == 0 && slot < H(s0, 2)) {
         decode(s0, slot, cur);
         issue_b(cur, H(s0, 1));
     }
@@ -446,18 +448,29 @@ __global__ __launch_bounds__(512) void chain_persist_kernel(const ChainStage *__
         const int kind = H(s0, 0), W = H(s0, 1), T = H(s0, 2);
         if (tr) { trace[st * 8 + 0] = wall_clock64(); trace[st * 8 + 6] = (unsigned long long)kind << 32 | (unsigned)T; }
         if (kind == 0) {
-            if (slot < T) issue_a(cur, W);   // its weights went out before the barrier
-            if (tr) trace[st * 8 + 1] = wall_clock64();
-            for (int t = slot; t < T; t += G) {
-                const int tn = t + G;
-                if (tn < T) {   // the next tile's operands fly under this tile's MFMAs, sum and epilogue
-                    decode(s0, tn, nxt);
-                    issue_b(nxt, W);
-                    issue_a(nxt, W);
+            if (PIPE) {
+                if (slot < T) issue_a(cur, W);   // its weights went out before the barrier
+                if (tr) trace[st * 8 + 1] = wall_clock64();
+                for (int t = slot; t < T; t += G) {
+                    const int tn = t + G;
+                    if (tn < T) {   // the next tile's operands fly under this tile's MFMAs, sum and epilogue
+                        decode(s0, tn, nxt);
+                        issue_b(nxt, W);
+                        issue_a(nxt, W);
+                    }
+                    finish(cur, W);
+                    cur = nxt;
+                    if (tr && t == slot) trace[st * 8 + 2] = wall_clock64();
                 }
-                finish(cur, W);
-                cur = nxt;
-                if (tr && t == slot) trace[st * 8 + 2] = wall_clock64();
+            } else {
+                if (tr) trace[st * 8 + 1] = wall_clock64();
+                for (int t = slot; t < T; t += G) {
+                    decode(s0, t, cur);
+                    issue_b(cur, W);
+                    issue_a(cur, W);
+                    finish(cur, W);
+                    if (tr && t == slot) trace[st * 8 + 2] = wall_clock64();
+                }
             }
         } else {
             const SampleParams &sp = stages[st].sp;
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(512) void chain_persist_kernel(const ChainStage *__
         if (tr) trace[st * 8 + 3] = wall_clock64();
         // before the barrier: the header + descriptors of stage st + 2, and the weights of this workgroup's first tile of stage st + 1
         fetch_stage(st + 2, s2);
-        if (st + 1 < nstages && H(s1, 0) == 0 && slot < H(s1, 2)) {
+        if (PIPE && st + 1 < nstages && H(s1, 0) == 0 && slot < H(s1, 2)) {
             decode(s1, slot, cur);
             issue_b(cur, H(s1, 1));
         }
@@ -496,7 +509,7 @@ void chain_record_set(ChainRecorder *r) { g_recorder = r; }
 // hold what the other needs.  Launches are chained through an event in submission order (the chains of passes on different
 // streams could not overlap anyway: each wants every CU).
 hipError_t launch_chain_persist(const ChainStage *stages, int nstages, ChainSync *sync, int clips, int wgs_per_cu, hipStream_t stream) {
-    if (!stages || !sync || nstages < 1 || clips % 128 != 0 || clips < 128 || clips > 512) return hipErrorInvalidValue;
+    if (!stages || !sync || nstages < 1 || (clips != 128 && clips != 256)) return hipErrorInvalidValue;
     int dev = 0, cus = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -527,10 +540,12 @@ hipError_t launch_chain_persist(const ChainStage *stages, int nstages, ChainSync
         trace = g_ctrace;
     }
     const int rb = clips / 128;
-    if (rb == 1) hipLaunchKernelGGL(chain_persist_kernel<1>, dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
-    else if (rb == 2) hipLaunchKernelGGL(chain_persist_kernel<2>, dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
-    else if (rb == 3) hipLaunchKernelGGL(chain_persist_kernel<3>, dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
-    else hipLaunchKernelGGL(chain_persist_kernel<4>, dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
+    const bool pipe = wgs_per_cu != 3;   // 3: the lean form (one workgroup per CU, no operand prefetch)
+    if (rb == 1 && pipe) hipLaunchKernelGGL((chain_persist_kernel<1, true>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
+    else if (rb == 1) hipLaunchKernelGGL((chain_persist_kernel<1, false>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
+    else if (rb == 2 && pipe) hipLaunchKernelGGL((chain_persist_kernel<2, true>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
+    else if (rb == 2) hipLaunchKernelGGL((chain_persist_kernel<2, false>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
+    else return hipErrorInvalidValue;
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return hipEventRecord(g_chain_done[dev], stream);
