@@ -33,7 +33,7 @@ def t(fns, n=N):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 a, b, c = t([chain]), t([conv]), t([chain, conv])
-print(f"TS_CHAIN_PERSIST={os.environ.get('TS_CHAIN_PERSIST', '0')} TS_CONV_ONE_PER_CU={os.environ.get('TS_CONV_ONE_PER_CU', '0')}: chain alone {a:.2f} ms, conv stacks alone {b:.2f} ms, "
+print(f"TS_CHAIN_PERSIST={os.environ.get('TS_CHAIN_PERSIST', '0')}: chain alone {a:.2f} ms, conv stacks alone {b:.2f} ms, "
       f"one of each together {c:.2f} ms (serial {a + b:.2f}, perfect overlap {max(a, b):.2f})")
 # timeline of the together case: start / end of every chain (stream A) and conv pass (stream B) against a common origin
 ev = lambda s: (e := torch.cuda.Event(enable_timing=True), e.record(s))[0]
