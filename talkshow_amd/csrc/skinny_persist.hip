@@ -42,7 +42,7 @@ __device__ __forceinline__ void l2_add(unsigned *p, unsigned v) {
 
 // all workgroups of this XCD have finished the stage (their stores are in the L2); false = timed out (another workgroup of
 // the XCD never arrived: the kernel gives up instead of hanging the device)
-__device__ __forceinline__ bool xcd_barrier(ChainSync *s, unsigned xcd, unsigned target) {
+__device__ __forceinline__ bool xcd_barrier(ChainSync *s, unsigned xcd, unsigned target, unsigned *abort_host) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ unsigned ok_sh;
@@ -55,6 +55,7 @@ __device__ __forceinline__ bool xcd_barrier(ChainSync *s, unsigned xcd, unsigned
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 200000000ull) {   // 2 s
                 s->abort_flag = 1;
+                __hip_atomic_store(abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host word: the next launch reports it
                 ok = 0;
                 break;
             }
@@ -190,7 +191,8 @@ struct TileOps {
 };
 
 template <int RB, bool PIPE>
-__global__ __launch_bounds__(512, PIPE ? 2 : 3) void chain_persist_kernel(const ChainStage *__restrict__ stages, const int nstages, ChainSync *sync, unsigned long long *trace) {
+__global__ __launch_bounds__(512, PIPE ? 2 : 3) void chain_persist_kernel(const ChainStage *__restrict__ stages, const int nstages, ChainSync *sync, unsigned long long *trace,
+                                                                      unsigned *abort_host) {
     constexpr int CB = 2, ROWS = RB * 16, NBLK = RB * CB, NREG = NBLK * 4, EMAX = RB * CB;   // EMAX = NREG / 4 (a W = 4 stage)
     __shared__ float red_raw[8 * NREG * 64];
     __shared__ float sf[256 + 1];
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 3) void chain_persist_kernel(const 
         }
         epoch += (unsigned)G;
         if (tr) trace[st * 8 + 4] = wall_clock64();
-        if (!xcd_barrier(sync, (unsigned)xcd, epoch)) return;
+        if (!xcd_barrier(sync, (unsigned)xcd, epoch, abort_host)) return;
         if (tr) trace[st * 8 + 5] = wall_clock64();
         s0 = s1;
         s1 = s2;
@@ -498,6 +500,7 @@ std::mutex g_chain_mu;
 unsigned long long *g_ctrace = nullptr;
 int g_ctrace_stages = 0;
 hipEvent_t g_chain_done[16] = {};
+unsigned *g_chain_abort[16] = {};   // pinned host words: set by a kernel that timed out at a barrier
 thread_local ChainRecorder *g_recorder = nullptr;
 
 }  // namespace
@@ -519,6 +522,15 @@ hipError_t launch_chain_persist(const ChainStage *stages, int nstages, ChainSync
     if (cus % 8 != 0 || cus < 8) return hipErrorInvalidValue;
     const int grid = cus * (wgs_per_cu == 2 ? 2 : 1);
     std::lock_guard<std::mutex> lock(g_chain_mu);
+    if (!g_chain_abort[dev]) {
+        e = hipHostMalloc((void **)&g_chain_abort[dev], sizeof(unsigned), hipHostMallocMapped);
+        if (e != hipSuccess) return e;
+        *g_chain_abort[dev] = 0;
+    }
+    if (*(volatile unsigned *)g_chain_abort[dev]) {   // an earlier launch gave up (2 s at a barrier): its codes are garbage — say so
+        *g_chain_abort[dev] = 0;
+        return hipErrorLaunchTimeOut;
+    }
     if (!g_chain_done[dev]) {
         e = hipEventCreateWithFlags(&g_chain_done[dev], hipEventDisableTiming);
         if (e != hipSuccess) return e;
@@ -541,10 +553,10 @@ hipError_t launch_chain_persist(const ChainStage *stages, int nstages, ChainSync
     }
     const int rb = clips / 128;
     const bool pipe = wgs_per_cu != 3;   // 3: the lean form (one workgroup per CU, no operand prefetch)
-    if (rb == 1 && pipe) hipLaunchKernelGGL((chain_persist_kernel<1, true>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
-    else if (rb == 1) hipLaunchKernelGGL((chain_persist_kernel<1, false>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
-    else if (rb == 2 && pipe) hipLaunchKernelGGL((chain_persist_kernel<2, true>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
-    else if (rb == 2) hipLaunchKernelGGL((chain_persist_kernel<2, false>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace);
+    if (rb == 1 && pipe) hipLaunchKernelGGL((chain_persist_kernel<1, true>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace, g_chain_abort[dev]);
+    else if (rb == 1) hipLaunchKernelGGL((chain_persist_kernel<1, false>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace, g_chain_abort[dev]);
+    else if (rb == 2 && pipe) hipLaunchKernelGGL((chain_persist_kernel<2, true>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace, g_chain_abort[dev]);
+    else if (rb == 2) hipLaunchKernelGGL((chain_persist_kernel<2, false>), dim3(grid), dim3(512), 0, stream, stages, nstages, sync, trace, g_chain_abort[dev]);
     else return hipErrorInvalidValue;
     e = hipGetLastError();
     if (e != hipSuccess) return e;
