@@ -125,6 +125,20 @@ def test_conv_banded_launch_matches_plain_tiles(hip):
     np.testing.assert_allclose(outs[0][:, rows, :], ref, atol=2e-5, rtol=1e-5)
 
 
+def test_clock_sampler_reports_a_plausible_shader_clock(hip):
+    """ts_debug_clock_sample (tools/conv_clock.py): shader cycles per 100 MHz wall-clock window on an idle device must come out
+    between 1 and 2.6 GHz (MI355X: 2.4 GHz nominal), window lengths at the requested 200 us."""
+    _lib, lib, ctx = hip
+    n, win = 20, 200
+    buf = torch.zeros(3 * n, dtype=torch.int64, device="cuda")
+    _lib.check(lib.ts_debug_clock_sample(_lib.dptr(buf), n, win, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    r = buf.cpu().numpy().reshape(n, 3).astype(np.float64)
+    ghz = r[:, 2] / (r[:, 1] * 10.0)
+    assert np.all(r[:, 1] >= win * 100) and np.all(r[:, 1] < 2 * win * 100)
+    assert np.all(ghz > 1.0) and np.all(ghz < 2.6), ghz
+
+
 def _fma32(a, b, c):
     """float32 fma emulated through float64 (the product is exact there; the second rounding differs from a true fma only in
     ~2^-29 of the cases)."""
