@@ -347,7 +347,13 @@ class Engine:
     def plan(self, steps):
         """How `steps` queued batches are grouped into passes: full passes of G batches, then the remainder.  (Spreading
         them evenly instead — 20 steps as 7, 7, 6 rather than 8, 8, 4 — measured 5 % SLOWER: a chain pass costs almost the
-        same for 192, 224 or 256 clips, so partly filled passes waste it.)"""
+        same for 192, 224 or 256 clips, so partly filled passes waste it; round 3 on one box, `tools/plan_env_ab.sh`: 8,8,4 1.57–1.58 M,
+        8,6,6 1.51, 6,6,8 1.51, 7,7,6 1.48 M frames/s.)"""
+        forced = os.environ.get("TS_BENCH_PLAN")           # A/B aid: "8,6,6" (must add up to the step count)
+        if forced:
+            p = [int(x) for x in forced.split(",")]
+            if sum(p) == steps and all(0 < x <= self.G for x in p):
+                return p
         full, rest = divmod(steps, self.G)
         return [self.G] * full + ([rest] if rest else [])
 
