@@ -2,6 +2,7 @@
 // skinny_wide.hip: 64 x 64 tiles staged through LDS).  A problem is 64 dwords: every wave fetches it with ONE vector
 // load (lane i holds word i) and pulls fields out with v_readlane — one round trip, no scalar-cache misses.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -53,6 +54,8 @@ struct ChainStage {
     SkinnyDesc d[SKINNY_MAX_PROBLEMS];
     SampleParams sp;
 };
+static_assert(offsetof(ChainStage, d) == 48 && offsetof(ChainStage, start) == 16,
+              "chain_persist_kernel reads the 12 header words (kind, W, ntiles, pad, start[8]) with one vector load in front of the descriptors");
 struct ChainSync {   // zeroed before every launch; one 128-byte line per counter
     unsigned slot[8][32];     // [xcd][0]: workgroups of the kernel that have started on this XCD
     unsigned arrive[8][32];   // [xcd][0]: arrivals at the stage barriers (monotonic)
