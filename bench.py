@@ -282,7 +282,7 @@ def chain_roofline(w, lib, _lib, stream, mfcc, ids, H, pmc_key):
             rec = json.load(open(pmc)).get(pmc_key, {})
             if rec.get("hbm_bytes_per_launch") is not None:
                 traffic = rec["hbm_bytes_per_launch"]
-                traffic_source = f"profiles/{name} [{pmc_key}] (rocprofv3 --pmc passes of tools/pmc_kernels.sh, recorded at commit {rec.get('commit', 'see git log of the file')}; not measured by this run)"
+                traffic_source = f"profiles/{name} [{pmc_key}] (rocprofv3 --pmc passes of tools/profile_r03.sh (r03) / tools/profile_r02.sh (r02), recorded at commit {rec.get('commit', 'see git log of the file')}; not measured by this run)"
                 break
     return {"kernel": "skinny_gemm_f32 (PixelCNN per-position GEMM chain)", "clips_per_stage": M, "bound": "mfma",
             "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
