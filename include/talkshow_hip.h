@@ -66,6 +66,11 @@ int ts_debug_clock_sample(unsigned long long *dev_out, int n, int window_us, voi
 /* Tuning aid: with TS_CHAIN_TRACE=1 one workgroup of the persistent chain kernel stamps the device wall clock (100 MHz) six times per
  * stage; this copies the last launch's records, 8 uint64 per stage (tools/persist_trace.py).  Returns the number of stages or -1. */
 int ts_debug_chain_trace(unsigned long long *out, int max_stages);
+/* Host-only helper (no GPU needed): how `conv_gemm_f32` launches an (M rows x N columns, `groups` problems) layer that takes 128 x 128
+ * tiles — out4 = {row blocks tiled 128 x 128, row blocks tiled 64 x 128, workgroups of the first band, workgroups in all}.  Returns 1 if the
+ * layer is launched in two bands (more than one round of 512 resident workgroups, not a whole number of rounds), 0 for a plain grid,
+ * -1 on a bad argument.  No reference counterpart. */
+int ts_debug_conv_bands(int M, int N, int groups, int *out4);
 /* Host-only helper (no GPU needed): the TILED copy of a row-major weight matrix W[N][ldw] (K columns used) that the
  * PixelCNN chain kernel multiplies with — every 16-column x 16-k operand fragment one contiguous KB in lane order
  * (DESIGN.md §3/§4); epi 0 = linear column order, 1 = gate (8 tanh channels + their 8 sigmoid partners per tile,

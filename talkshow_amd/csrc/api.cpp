@@ -1,4 +1,5 @@
 // Whole-wrapper entry points and the single-operator entry points used by the kernel-level parity tests.
+#include <cstring>
 #include <vector>
 #include "host_common.h"
 #include "skinny_desc.h"
@@ -69,6 +70,20 @@ int ts_debug_clock_sample(unsigned long long *dev_out, int n, int window_us, voi
 }
 // tuning aid (TS_CHAIN_TRACE=1): per-stage wall-clock stamps of the persistent chain kernel's last launch, 8 uint64 per stage
 int ts_debug_chain_trace(unsigned long long *out, int max_stages) { return ts::chain_trace_read(out, max_stages); }
+// Host-only (no GPU): the launch plan of an (M x N, `groups` problems) conv layer — out4 = {row blocks of 128 x 128 tiles, row blocks of
+// 64 x 128 tiles, workgroups of the first band, workgroups}; returns 1 if the layer is launched in two bands, 0 for a plain grid
+int ts_debug_conv_bands(int M, int N, int groups, int *out4) {
+    if (M < 1 || N < 1 || groups < 1 || groups > 4 || !out4) return fail("ts_debug_conv_bands: bad argument") ? -1 : -1;
+    ts::ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.M = M;
+    p.N = N;
+    p.ngroups = groups;
+    ts::ConvBands bd{};
+    const bool banded = ts::conv_gemm_band_plan(p, bd);
+    out4[0] = bd.mt_big; out4[1] = bd.mt_small; out4[2] = bd.first_small; out4[3] = bd.total;
+    return banded ? 1 : 0;
+}
 int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int gateD, float *out) {
     if (!W || !out || N < 1 || K < 16 || K % 16 || ldw < K) return fail("ts_debug_tile_weights: bad argument");
     if (epi == ts::EPI_GATE && (gateD < 8 || gateD % 8 || N % (2 * gateD))) return fail("ts_debug_tile_weights: gate tiles need gateD % 8 == 0 and N % (2 gateD) == 0");

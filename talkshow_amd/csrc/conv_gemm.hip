@@ -384,6 +384,9 @@ static bool plan_bands(const ConvParams &p, ConvBands &bd) {
     return true;
 }
 
+// host-only view of the launch plan (tests): would `launch_conv_gemm(p, 0, ...)` band this layer, and how
+bool conv_gemm_band_plan(const ConvParams &p, ConvBands &bd) { return pick_tile(p) == 1 && plan_bands(p, bd); }
+
 hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream) {
     ConvParams p = p_in;
     if (!p.zero) {

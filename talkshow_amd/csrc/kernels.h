@@ -56,6 +56,7 @@ struct ConvBands {
     int mt_big, mt_small, first_small, total;
 };
 
+bool conv_gemm_band_plan(const ConvParams &p, ConvBands &bd);   // host only: the plan launch_conv_gemm(p, 0, ...) would use
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 (BK 64), 6 = 160x128, 7 = 96x128 (for tuning / tests)
 hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream);
 // the same convolution on the bf16 matrix cores with fp32 operands split into `planes` bf16 terms (2: three products, ~2^-16;

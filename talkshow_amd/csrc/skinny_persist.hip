@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 3) void chain_persist_kernel(const 
     // ---- activations of the wave's K slice (after the barrier) ----
     auto issue_a = [&](TileOps<RB, CB> &o, int W) {
         if (wave >= W) return;
-        const int dw = o.dw, mt = o.mt, cnt = CH_I(dw, SD_CNT), q0 = wave * cnt, M = CH_I(dw, SD_M), N = CH_I(dw, SD_N);
+        const int dw = o.dw, mt = o.mt, cnt = CH_I(dw, SD_CNT), q0 = wave * cnt, M = CH_I(dw, SD_M);
         int sbase = SD_SEG, qs = 0;
         {
             const int nseg = CH_I(dw, SD_NSEG);

@@ -183,6 +183,41 @@ def test_tiled_weight_layout_gate():
         _lib.check(lib.ts_debug_tile_weights(W.ctypes.data_as(C.c_void_p), N, 24, K, 0, 0, out.ctypes.data_as(C.c_void_p)))
 
 
+def test_conv_band_plan_covers_every_row_once():
+    """conv_gemm_f32 launches layers of more than one round of 512 resident workgroups in two bands: 128 x 128 tiles for whole
+    rounds, 64 x 128 tiles for the rows that are left (host logic, no GPU).  The bands must tile the rows exactly once, the
+    first band must be a whole number of rounds short of at most one row block, and layers that fit one round or come to
+    whole rounds keep the plain grid."""
+    import ctypes as C
+    from talkshow_amd import _lib
+    lib = _lib.load()
+    out = (C.c_int * 4)()
+    banded = 0
+    for M in (300, 4096, 19200, 19227, 38400, 76800, 65536, 100000):
+        for N in (64, 256, 500, 512, 1024, 2048):
+            for groups in (1, 2, 4):
+                r = lib.ts_debug_conv_bands(M, N, groups, out)
+                assert r in (0, 1)
+                MT, NT = -(-M // 128), -(-N // 128) * groups
+                if r == 0:
+                    continue
+                banded += 1
+                mt_big, mt_small, first_small, total = list(out)
+                assert MT * NT > 512 and (MT * NT) % 512 != 0
+                assert 0 < mt_big < MT and mt_small > 0
+                assert first_small == mt_big * NT and total == first_small + mt_small * NT
+                rounds = (MT * NT) // 512
+                assert rounds * 512 - NT < first_small <= rounds * 512            # whole rounds, short of less than one row block
+                left = M - mt_big * 128
+                assert 0 < left <= mt_small * 64 < left + 64                       # the small band ends within its last row block
+    assert banded > 20
+    # the bench's paired 1024-channel layers: 19 200 rows x 1 024 columns x 2 problems = 2 400 tiles = 4.69 rounds
+    assert lib.ts_debug_conv_bands(19200, 1024, 2, out) == 1 and list(out) == [128, 44, 2048, 2048 + 44 * 16]
+    assert lib.ts_debug_conv_bands(4096, 4096, 1, out) == 0                        # 1 024 tiles: two whole rounds
+    assert lib.ts_debug_conv_bands(2400, 1024, 2, out) == 0                        # 304 tiles: one round
+    assert lib.ts_debug_conv_bands(0, 64, 1, out) == -1
+
+
 def test_bench_pass_plan():
     """bench.py groups the queued 32-clip steps into chain passes: full passes of G batches, then the remainder — the
     driver's `--steps 20` at G = 8 is 8 + 8 + 4, every step is run exactly once."""
