@@ -308,10 +308,47 @@ def conv_roofline(lib, _lib, local, run_pass):
             "avg_launch_us": msf[0] * 1e3 / nf[0], "ms_per_pass": msf[0]}
 
 
+def whole_body_block(w, _lib, local, batch_body):
+    """BASELINE configs[4] at ONE rank, as extra information in the default line: 128 clips per step, whole body =
+    body_pixel greedy (one coalesced pass) + face generator (2 batches of 64) -> (128, 300, 265) rows assembled on the GPU; fp32
+    (the parity path) and, beside it, the opt-in bf16x3 plan of the face GEMMs.  The multi-rank form of the same step is
+    `bench.py --config whole_body` (one all-gather of the rows per step)."""
+    import types
+    from talkshow_amd import parallel, synth
+    face = types.SimpleNamespace(generator=build_face(local))
+    dev = torch.device("cuda", local)
+    n, T = 128, FRAMES_PER_CLIP
+    mfcc = torch.from_numpy(synth.mfcc_features(4000, n, T)).to(dev)
+    ids = torch.from_numpy(synth.speaker_ids(n)).to(dev)
+    wav = torch.from_numpy(synth.wav16(5000, n, 160000)).to(dev)
+    fid = torch.nn.functional.one_hot(torch.arange(n) % 4, 4).float().to(dev)
+
+    def step():
+        return parallel.whole_body_local(w, face, mfcc, ids, wav, fid, mode=_lib.TS_SAMPLE_GREEDY, clip_index0=0,
+                                         batch_body=batch_body, batch_face=64)
+    rows = step()
+    torch.cuda.synchronize()
+    assert tuple(rows.shape) == (n, T, 265) and bool(torch.isfinite(rows).all())
+    t32 = timed(step)
+    out = {"workload": f"BASELINE configs[4] at one rank: {n} synthetic 10 s clips per step, body_pixel greedy (one pass of {min(n, batch_body)} "
+                       "clips) + face generator (batches of 64) -> (128, 300, 265) rows; no exchange at N = 1",
+           "fp32": {"ms_per_step": t32 * 1e3, "frames_per_s": n * T / t32}}
+    try:
+        face.generator.set_arith(3)
+        rows3 = step()
+        torch.cuda.synchronize()
+        t3 = timed(step)
+        out["face_bf16x3_opt_in"] = {"ms_per_step": t3 * 1e3, "frames_per_s": n * T / t3,
+                                     "max_abs_delta_vs_fp32_rows": float((rows3 - rows).abs().max().item())}
+    finally:
+        face.generator.set_arith(0)
+    return out
+
+
 class Engine:
     """configs[1] executor: submit() a 32-clip batch per step; groups of G batches run as one pass on alternating streams."""
 
-    def __init__(self, w, lib, _lib, streams, B, T, G, mfcc, gt, ids, rank, enc_streams=None):
+    def __init__(self, w, lib, _lib, streams, B, T, G, mfcc, gt, ids, rank, enc_streams=None, pcie=False):
         self.w, self.lib, self._lib = w, lib, _lib
         S = len(streams)
         self.B, self.T, self.H, self.G, self.S = B, T, T // 4, G, S
@@ -321,11 +358,24 @@ class Engine:
         self.enc_streams = enc_streams     # optional: the VQ-encode half of a pass on its own stream(s) (it feeds nothing downstream)
         self.ids_rep = ids.repeat(G).contiguous()
         self.gt_codes = [torch.empty((B * G, self.H, 2), dtype=torch.int64, device=self.dev) for _ in range(S)]
-        self.last = None
+        self.last = self.last_group = None
+        self.pcie = pcie
+        if pcie:
+            # PCIe-inclusive mode: the batches live in pinned host memory; per stream one device staging set + pinned result buffers
+            pin = lambda t: t.cpu().pin_memory()
+            self.h_mfcc, self.h_gt = [pin(t) for t in mfcc], [pin(t) for t in gt]
+            n = B * G
+            self.d_mfcc = [torch.empty((n, T, 64), dtype=torch.float32, device=self.dev) for _ in range(S)]
+            self.d_gt = [torch.empty((n, T, gt[0].shape[-1]), dtype=torch.float32, device=self.dev) for _ in range(S)]
+            self.h_poses = [torch.empty((n, T, gt[0].shape[-1]), dtype=torch.float32).pin_memory() for _ in range(S)]
+            self.h_codes = [torch.empty((2, n, self.H, 2), dtype=torch.int64).pin_memory() for _ in range(S)]
 
     def run_group(self, ks, stream_index):
         NB, B, T, lib, _lib, w = len(self.mfcc), self.B, self.T, self.lib, self._lib, self.w
         n = B * len(ks)
+        self.last_group = (list(ks), stream_index)
+        if self.pcie:
+            return self.run_group_pcie(ks, stream_index)
 
         def encode():
             # VQ-VAE encode half of configs[1] (VQVAE.encode of the 300 GT frames, body and hand)
@@ -343,6 +393,27 @@ class Engine:
             # audio encoder -> PixelCNN greedy -> VQ decode
             self.last = w.generate_batch(mfc, self.ids_rep[:n], mode=_lib.TS_SAMPLE_GREEDY, clip_index0=self.rank * B)
         return self.last
+
+    def run_group_pcie(self, ks, si):
+        """run_group with the pass's inputs copied in from pinned host memory and its results copied out to pinned host memory,
+        all on the pass's stream (the copies of one pass overlap the compute of the passes on the other streams)."""
+        NB, B, T, lib, _lib, w = len(self.mfcc), self.B, self.T, self.lib, self._lib, self.w
+        n = B * len(ks)
+        with torch.cuda.stream(self.streams[si]):
+            for j, k in enumerate(ks):
+                self.d_mfcc[si][j * B:(j + 1) * B].copy_(self.h_mfcc[k % NB], non_blocking=True)
+                self.d_gt[si][j * B:(j + 1) * B].copy_(self.h_gt[k % NB], non_blocking=True)
+            _lib.check(lib.ts_body_vq_infer(w.g_body.handle(), w.g_hand.handle(), _lib.dptr(self.d_gt[si][:n]), n, T,
+                                            _lib.dptr(self.gt_codes[si][:n]), None, _lib.stream_ptr()))
+            self.last = w.generate_batch(self.d_mfcc[si][:n], self.ids_rep[:n], mode=_lib.TS_SAMPLE_GREEDY, clip_index0=self.rank * B)
+            self.h_poses[si][:n].copy_(self.last[1], non_blocking=True)
+            self.h_codes[si][0, :n].copy_(self.last[0], non_blocking=True)
+            self.h_codes[si][1, :n].copy_(self.gt_codes[si][:n], non_blocking=True)
+        return self.last
+
+    def pcie_bytes_per_step(self):
+        B, T, C = self.B, self.T, self.gt[0].shape[-1]
+        return B * T * 64 * 4 + 2 * B * T * C * 4 + 2 * B * self.H * 2 * 8
 
     def plan(self, steps):
         """How `steps` queued batches are grouped into passes: full passes of G batches, then the remainder.  (Spreading
@@ -449,6 +520,206 @@ def main_whole_body(a, world, rank, local, dist):
         print(json.dumps(out), flush=True)
 
 
+class BodyJob:
+    """configs[1] on this rank's GPU: what `run_contract` drives (tests/test_bench_control_flow.py drives the same function under
+    gloo with a device-free stand-in of this class)."""
+
+    def __init__(self, a, world, rank, local):
+        from talkshow_amd import _lib, synth
+        self.a, self.world, self.rank, self.local = a, world, rank, local
+        self._lib, self.lib = _lib, _lib.load()
+        self.w, self.sds = build_models(local)
+        B, T = a.batch, FRAMES_PER_CLIP
+        self.B, self.T, self.H = B, T, T // 4
+        self.dev = torch.device("cuda", local)
+        # a few distinct resident input batches, cycled; rank r owns global clips [r*B, (r+1)*B) of each step
+        self.NB = 3
+        self.mfcc = [torch.from_numpy(synth.mfcc_features(1000 + 10 * rank + k, B, T)).to(self.dev) for k in range(self.NB)]
+        self.gt = [torch.from_numpy(synth.gt_poses(2000 + 10 * rank + k, B, T)).to(self.dev) for k in range(self.NB)]
+        self.ids = torch.from_numpy(synth.speaker_ids(B)).to(self.dev)
+        self.G, self.S = max(1, a.coalesce), max(1, a.streams)
+        # one pool of library streams, created back to back (distinct hardware queues); every execution mode draws from it
+        self.pool = _lib.create_streams(max(self.S, 1 if a.no_modes else 4), local)
+        enc_pool = _lib.create_streams(a.enc_streams, local) if a.enc_streams > 0 else None
+        self.eng = Engine(self.w, self.lib, _lib, self.pool[:self.S], B, T, self.G, self.mfcc, self.gt, self.ids, rank,
+                          enc_streams=enc_pool)
+
+    def warm(self, steps):
+        torch.cuda.synchronize()
+        self.eng.warm(steps)
+
+    def run_steps(self, k):
+        return self.eng.run_steps(k)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def scalar(self, x):
+        return torch.tensor([x], dtype=torch.float64, device=self.dev)
+
+    def gather(self):
+        """the ONE exchange of the job (north_star): every generated sequence of every step, (steps * 32, 300, 129) per rank,
+        all-gathered to (N * steps * 32, 300, 129) on every rank"""
+        from talkshow_amd.parallel import gather_sequences
+        rows = self.eng.all_rows()
+        allp = gather_sequences(rows)
+        return {"gather_bytes_per_rank": int(rows.numel() * 4), "gathered_shape": list(allp.shape)}
+
+    def frames_per_step(self):
+        return self.B * FRAMES_PER_CLIP
+
+    def describe(self):
+        B, G, S = self.B, self.G, self.S
+        return {"workload": "BASELINE configs[1]: batch=32 x 10 s clips, body+hand VQ-VAE encode -> PixelCNN greedy decode -> VQ decode, 30 fps",
+                "batch_per_gpu": B, "frames_per_clip": FRAMES_PER_CLIP, "coalesce": G, "streams": S,
+                "batches_per_pass": self.eng.plan(self.a.steps),
+                "parallelism": f"clip-sharded x{self.world}; per GPU the queued batches run as passes of up to {G} batches "
+                               f"({B * G} clips), {S} passes in flight (one HIP stream each)"}
+
+    def selfcheck(self):
+        """Outside the timed region: the LAST timed pass's outputs against the same clips run alone, one 32-clip batch on one
+        stream (the strict mode) — generated codes, poses and the VQ-encode codes must be bit-equal (a clip's result does not
+        depend on how its batch was grouped), so a skipped or mis-ordered launch inside the timed region cannot pass as a
+        better number.  Raises on a mismatch: a wrong result must not leave a bench line behind."""
+        eng, B, _lib = self.eng, self.B, self._lib
+        ks, si = eng.last_group
+        codes, poses = eng.last
+        gtc = eng.gt_codes[si][:B * len(ks)]
+        checked = []
+        for j in sorted({0, len(ks) - 1}):
+            k = ks[j]
+            with torch.cuda.stream(self.pool[0]):
+                c1, p1 = self.w.generate_batch(self.mfcc[k % self.NB], self.ids, mode=_lib.TS_SAMPLE_GREEDY, clip_index0=self.rank * B)
+                g1 = torch.empty((B, self.H, 2), dtype=torch.int64, device=self.dev)
+                _lib.check(self.lib.ts_body_vq_infer(self.w.g_body.handle(), self.w.g_hand.handle(), _lib.dptr(self.gt[k % self.NB]), B,
+                                                     self.T, _lib.dptr(g1), None, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            sl = slice(j * B, (j + 1) * B)
+            same = (torch.equal(codes[sl], c1), torch.equal(poses[sl], p1), torch.equal(gtc[sl], g1))
+            if not all(same):
+                raise RuntimeError(f"bench selfcheck FAILED for step {k} (batch {j} of the last pass of {len(ks)}): generated codes equal "
+                                   f"{same[0]}, poses equal {same[1]}, VQ-encode codes equal {same[2]}")
+            if not (torch.isfinite(p1).all() and int(c1.min()) >= 0 and int(c1.max()) < 2048 and int(g1.min()) >= 0 and int(g1.max()) < 2048):
+                raise RuntimeError("bench selfcheck FAILED: outputs out of range")
+            checked.append(int(k))
+        return {"selfcheck": "ok", "selfcheck_what": f"steps {checked} of the last timed pass ({len(ks)} batches on stream {si}) re-run alone as "
+                "one 32-clip batch: generated codes, poses and VQ-encode codes bit-equal"}
+
+    def extras(self, out):
+        """rank 0's measurement legs beside the headline; no process group is alive while these run"""
+        a, w, lib, _lib, eng, B, T, G, S = self.a, self.w, self.lib, self._lib, self.eng, self.B, self.T, self.G, self.S
+        mfcc, gt, ids, rank, pool, NB, H = self.mfcc, self.gt, self.ids, self.rank, self.pool, self.NB, self.H
+        # the same workload under the other execution modes, for comparison (not the headline)
+        if not a.no_modes:
+            modes = {}
+            one = Engine(w, lib, _lib, pool[:1], B, T, 1, mfcc, gt, ids, rank)
+            one.warm(1)
+            lat = timed(lambda: one.run_steps(1))
+            modes["one_batch_in_flight"] = {"what": "strict: one 32-clip batch at a time, one stream (= latency of a batch)",
+                                            "ms_per_step": lat * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / lat}
+            out["batch_latency_ms"] = lat * 1e3
+            r01 = Engine(w, lib, _lib, pool[:4], B, T, 1, mfcc, gt, ids, rank)
+            r01.warm(1)
+            t4 = timed(lambda: r01.run_steps(16)) / 16
+            modes["four_streams_no_coalescing"] = {"what": "round-1 mode: 4 independent 32-clip batches on 4 HIP streams",
+                                                   "ms_per_step": t4 * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / t4}
+            tg = timed(lambda: eng.run_steps(G * S)) / (G * S)
+            modes["coalesced"] = {"what": f"headline mode re-measured: passes of {B * G} clips on {S} streams",
+                                  "ms_per_step": tg * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / tg,
+                                  "latency_of_a_pass_ms": timed(lambda: eng.run_group(list(range(G)), 0)) * 1e3}
+            # the same passes with every step's inputs arriving from, and its outputs leaving to, pinned HOST memory inside the
+            # timed region (the reference hands numpy arrays in and out: `value` is the resident-input figure, this is the other)
+            try:
+                pc = Engine(w, lib, _lib, pool[:S], B, T, G, mfcc, gt, ids, rank, pcie=True)
+                pc.warm(G * S)
+                tp = timed(lambda: pc.run_steps(G * S)) / (G * S)
+                modes["pcie_inclusive"] = {"what": f"coalesced mode with per-pass H2D of the MFCC + GT-pose batches and D2H of poses + both code "
+                                                   f"grids from / to pinned host memory on the pass's stream ({pc.pcie_bytes_per_step() / 1e6:.1f} MB per step)",
+                                           "ms_per_step": tp * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / tp, "vs_resident": tg / tp}
+            except Exception as e:
+                modes["pcie_inclusive"] = {"error": repr(e)}
+            out["modes"] = modes
+
+        if not a.no_roofline:
+            big_mf = torch.cat([mfcc[k % NB] for k in range(G)], 0) if G > 1 else mfcc[0]
+            out["roofline"] = chain_roofline(w, lib, _lib, eng.streams[0], big_mf, eng.ids_rep, H, f"skinny_gemm_f32_M{B * G}")
+            if G > 1:
+                out["roofline_one_batch"] = chain_roofline(w, lib, _lib, eng.streams[0], mfcc[0], ids, H, f"skinny_gemm_f32_M{B}")
+            out["roofline_conv_gemm"] = conv_roofline(lib, _lib, self.local, lambda: eng.run_group(list(range(G)), 0))
+        if not a.no_face and self.world == 1:
+            for key, fn in (("diversity", lambda: diversity_block(w, _lib, mfcc[0])), ("frontend", lambda: frontend_block(w, _lib, B * G)),
+                            ("face", lambda: face_block(self.local)), ("whole_body", lambda: whole_body_block(w, _lib, self.local, B * G))):
+                try:
+                    out[key] = fn()
+                except Exception as e:                   # extra information; never lose the main line
+                    out[key] = {"error": repr(e)}
+        if self.world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(self.sds, 1000)
+
+
+def run_contract(job, dist, world, rank, steps, warmup, clock=time.perf_counter):
+    """The bench contract's control flow, device-agnostic: W untimed warm-up steps, then EXACTLY `steps` steps bracketed by
+    barrier + synchronize on both sides, the job's one exchange inside the bracket (N > 1), MAX over ranks.  Every collective
+    of the job sits in here; the caller destroys the process group before rank 0 starts its extra measurement legs, so no rank
+    ever waits in a collective for them.  Returns (seconds, compute seconds on this rank, exchange info or None)."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    job.warm(steps)
+    job.run_steps(max(warmup, 1))            # W untimed steps (passes of sizes the warm-up above has seen or captures now)
+    job.sync()
+    if world > 1:
+        job.gather()                         # the exchange once untimed: RCCL sets up its rings / buffers on first use
+        job.sync()
+    barrier()
+    t0 = clock()
+    job.run_steps(steps)
+    job.sync()
+    t_compute = clock() - t0
+    info = None
+    if world > 1:
+        info = job.gather()
+        job.sync()
+        info.update({"ranks_seen": world, "gather_ms": (clock() - t0 - t_compute) * 1e3, "compute_ms": t_compute * 1e3,
+                     "note": "rank 0's clock; the headline takes the max over ranks of compute + gather"})
+    barrier()
+    dt = clock() - t0
+    if world > 1:
+        tmax = job.scalar(dt)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt, t_compute, info
+
+
+def finish(job, dist, world, rank, steps, warmup, dt, info, emit=print):
+    """After the timed region: every rank checks what it timed (local work), the ranks leave the process group TOGETHER, and only
+    then does rank 0 run its extra legs and print the one JSON line.  Ranks != 0 run nothing else."""
+    check = job.selfcheck()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    frames = world * steps * job.frames_per_step()
+    out = {
+        "metric": "generated SMPL-X frames/sec (10 s @ 30 fps clips), whole job",
+        "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded MFCC-scale features / poses, random-init weights of the reference architecture)",
+        "config": job.describe(),
+        "per_gpu_frames_per_s": frames / dt / world,
+        "rccl": info,      # N > 1: the job's one all-gather, timed apart from the compute (null at N = 1); unmeasured on hardware until SCALE runs
+    }
+    out.update(check)
+    # whole path against the fp32 MFMA roof: algorithmic work of configs[1] (SURVEY.md §8d: 64.25 MFLOP per generated frame)
+    ach = ALG_FLOP_PER_FRAME * frames / dt / world / 1e12
+    out["whole_path"] = {"algorithmic_TFLOPs_per_gpu": ach, "frac_of_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS}
+    job.extras(out)
+    emit(json.dumps(out))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -485,121 +756,9 @@ def main():
             dist.destroy_process_group()
         return
 
-    from talkshow_amd import _lib, synth
-    from talkshow_amd.parallel import gather_sequences
-    lib = _lib.load()
-    w, sds = build_models(local)
-    B, T = a.batch, FRAMES_PER_CLIP
-    dev = torch.device("cuda", local)
-    # a few distinct resident input batches, cycled; rank r owns global clips [r*B, (r+1)*B) of each step
-    NB = 3
-    mfcc = [torch.from_numpy(synth.mfcc_features(1000 + 10 * rank + k, B, T)).to(dev) for k in range(NB)]
-    gt = [torch.from_numpy(synth.gt_poses(2000 + 10 * rank + k, B, T)).to(dev) for k in range(NB)]
-    ids = torch.from_numpy(synth.speaker_ids(B)).to(dev)
-    H = T // 4
-    G, S = max(1, a.coalesce), max(1, a.streams)
-    # one pool of library streams, created back to back (distinct hardware queues); every execution mode draws from it
-    pool = _lib.create_streams(max(S, 1 if a.no_modes else 4), local)
-    enc_pool = _lib.create_streams(a.enc_streams, local) if a.enc_streams > 0 else None
-    eng = Engine(w, lib, _lib, pool[:S], B, T, G, mfcc, gt, ids, rank, enc_streams=enc_pool)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    torch.cuda.synchronize()
-    eng.warm(a.steps)
-    _, wposes = eng.run_steps(max(a.warmup, 1))       # W untimed steps (passes of sizes the warm-up above has seen or captures now)
-    torch.cuda.synchronize()
-    if world > 1:
-        gather_sequences(eng.all_rows())               # the exchange once untimed: RCCL sets up its rings / buffers on first use
-        torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    codes, poses = eng.run_steps(a.steps)
-    torch.cuda.synchronize()
-    t_compute = time.perf_counter() - t0
-    rccl = None
-    if world > 1:
-        # the ONE exchange of the job (north_star): every generated sequence of every step, (steps * 32, 300, 129) per rank,
-        # all-gathered to (N * steps * 32, 300, 129) on every rank — inside the timed region
-        rows = eng.all_rows()
-        all_poses = gather_sequences(rows)
-        torch.cuda.synchronize()
-        rccl = {"ranks_seen": world, "gather_bytes_per_rank": int(rows.numel() * 4), "gathered_shape": list(all_poses.shape),
-                "gather_ms": (time.perf_counter() - t0 - t_compute) * 1e3, "compute_ms": t_compute * 1e3,
-                "note": "rank 0's clock; the headline takes the max over ranks of compute + gather"}
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    frames = world * a.steps * B * FRAMES_PER_CLIP
-    out = {
-        "metric": "generated SMPL-X frames/sec (10 s @ 30 fps clips), whole job",
-        "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded MFCC-scale features / poses, random-init weights of the reference architecture)",
-        "config": {"workload": "BASELINE configs[1]: batch=32 x 10 s clips, body+hand VQ-VAE encode -> PixelCNN greedy decode -> VQ decode, 30 fps",
-                   "batch_per_gpu": B, "frames_per_clip": FRAMES_PER_CLIP, "coalesce": G, "streams": S,
-                   "batches_per_pass": eng.plan(a.steps),
-                   "parallelism": f"clip-sharded x{world}; per GPU the queued batches run as passes of up to {G} batches "
-                                  f"({B * G} clips), {S} passes in flight (one HIP stream each)"},
-        "per_gpu_frames_per_s": frames / dt / world,
-        "rccl": rccl,      # N > 1: the job's one all-gather, timed apart from the compute (null at N = 1); unmeasured on hardware until SCALE runs
-    }
-    # whole path against the fp32 MFMA roof: algorithmic work of configs[1] (64.25 MFLOP per generated frame)
-    ach = ALG_FLOP_PER_FRAME * frames / dt / world / 1e12
-    out["whole_path"] = {"algorithmic_TFLOPs_per_gpu": ach, "frac_of_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS}
-
-    # the same workload under the other execution modes, for comparison (not the headline)
-    if not a.no_modes:
-        modes = {}
-        one = Engine(w, lib, _lib, pool[:1], B, T, 1, mfcc, gt, ids, rank)
-        one.warm(1)
-        lat = timed(lambda: one.run_steps(1))
-        modes["one_batch_in_flight"] = {"what": "strict: one 32-clip batch at a time, one stream (= latency of a batch)",
-                                        "ms_per_step": lat * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / lat}
-        out["batch_latency_ms"] = lat * 1e3
-        r01 = Engine(w, lib, _lib, pool[:4], B, T, 1, mfcc, gt, ids, rank)
-        r01.warm(1)
-        t4 = timed(lambda: r01.run_steps(16)) / 16
-        modes["four_streams_no_coalescing"] = {"what": "round-1 mode: 4 independent 32-clip batches on 4 HIP streams",
-                                               "ms_per_step": t4 * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / t4}
-        tg = timed(lambda: eng.run_steps(G * S)) / (G * S)
-        modes["coalesced"] = {"what": f"headline mode re-measured: passes of {B * G} clips on {S} streams",
-                              "ms_per_step": tg * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / tg,
-                              "latency_of_a_pass_ms": timed(lambda: eng.run_group(list(range(G)), 0)) * 1e3}
-        out["modes"] = modes
-
-    if rank == 0 and not a.no_roofline:
-        big_mf = torch.cat([mfcc[k % NB] for k in range(G)], 0) if G > 1 else mfcc[0]
-        out["roofline"] = chain_roofline(w, lib, _lib, eng.streams[0], big_mf, eng.ids_rep, H, f"skinny_gemm_f32_M{B * G}")
-        if G > 1:
-            out["roofline_one_batch"] = chain_roofline(w, lib, _lib, eng.streams[0], mfcc[0], ids, H, f"skinny_gemm_f32_M{B}")
-        out["roofline_conv_gemm"] = conv_roofline(lib, _lib, local, lambda: eng.run_group(list(range(G)), 0))
-    if rank == 0 and not a.no_face:
-        try:
-            out["diversity"] = diversity_block(w, _lib, mfcc[0])
-        except Exception as e:
-            out["diversity"] = {"error": repr(e)}
-        try:
-            out["frontend"] = frontend_block(w, _lib, B * G)
-        except Exception as e:
-            out["frontend"] = {"error": repr(e)}
-        try:
-            out["face"] = face_block(local)
-        except Exception as e:                       # the face line is extra information; never lose the main line
-            out["face"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sds, 1000)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()          # rank 0's extra measurement legs are over: leave together
-        dist.destroy_process_group()
+    job = BodyJob(a, world, rank, local)
+    dt, _, info = run_contract(job, dist, world, rank, a.steps, a.warmup)
+    finish(job, dist, world, rank, a.steps, a.warmup, dt, info, emit=lambda line: print(line, flush=True))
 
 
 if __name__ == "__main__":

@@ -208,6 +208,11 @@ int ts_op_linear(ts_ctx *ctx, const float *x_dev, int M, int K, const float *w_h
  * TS_SAMPLE_UNIFORMS (uniforms_dev (B)). */
 int ts_op_sample(ts_ctx *ctx, const float *logits_dev, int B, int V, int mode, const float *uniforms_dev,
                  int64_t *idx_dev, void *stream);
+/* the same draw in TS_SAMPLE_PHILOX mode (softmax + multinomial(1) of gated_pixelcnn_v2.py:173-176 with the library's own
+ * random stream): row b draws with u = Philox4x32-10(key = seed; counter = (position, clip_index0 + b, 0)) >> 8 * 2^-24,
+ * exactly what ts_pixelcnn_generate uses for clip clip_index0 + b at grid position row * 2 + column. */
+int ts_op_sample_philox(ts_ctx *ctx, const float *logits_dev, int B, int V, uint64_t seed, int64_t clip_index0,
+                        uint32_t position, int64_t *idx_dev, void *stream);
 
 /* Output assembly the callers do after both generators (scripts/demo.py:207-229 + data_utils/lower_body.py:68-87
  * `part2full`): body_dev (B,Tb,129) body+hand poses, face_dev (B,Tf,103) jaw(3)+expression(100) -> out_dev (B,Tf,265).

@@ -294,20 +294,37 @@ def pixelcnn_generate(label, aud, sd, n_layers, H, uniforms=None, return_logits=
     return x
 
 
+def det_expf(x):
+    """exp(x) for x <= 0 exactly as the HIP sampler computes it (`csrc/vq.hip::det_expf`): fp32 multiplies and adds only, one
+    IEEE rounding each, no fused multiply-add — numpy's float32 arithmetic gives the same bits on any host.  Cody-Waite
+    reduction by ln 2, Cephes' degree-5 polynomial, 2^n by exponent; arguments below -86 give 0."""
+    x = np.asarray(x, F32)
+    n = np.rint(x * F32(1.44269504088896341)).astype(F32)
+    r = (x - n * F32(0.693145751953125)).astype(F32)
+    r = (r - n * F32(1.42860682030941723212e-6)).astype(F32)
+    q = np.full_like(r, F32(1.9875691500e-4))
+    for c in (1.3981999507e-3, 8.3334519073e-3, 4.1665795894e-2, 1.6666665459e-1, 5.0000001201e-1):
+        q = (q * r + F32(c)).astype(F32)          # numpy rounds the product, then the sum: two fp32 operations
+    y = (q * (r * r) + r).astype(F32)
+    y = (y + F32(1.0)).astype(F32)
+    out = (y * np.ldexp(F32(1.0), np.maximum(n, -126).astype(np.int32)).astype(F32)).astype(F32)
+    return np.where(x < F32(-86.0), F32(0.0), out).astype(F32)
+
+
 def sample_inverse_cdf(logits, u, nthreads=256):
     """Draw from softmax(logits) with a given uniform: first index whose running sum of exp(l - max) exceeds u * total.
 
     The reference draws with `probs.multinomial(1)` (`gated_pixelcnn_v2.py:173-176`); any exact inverse-CDF draw has that
     distribution.  The summation STRUCTURE below is the one the HIP sampler uses (so draws compare bit for bit):
     `nthreads` contiguous chunks summed left to right, chunk sums prefix-summed left to right, then a left-to-right walk
-    inside the owning chunk; all in float32.
+    inside the owning chunk; all in float32, the exponential included (`det_expf`).
     """
     B, V = logits.shape
     chunk = (V + nthreads - 1) // nthreads
     out = np.zeros(B, np.int64)
     for b in range(B):
         m = logits[b].max()
-        e = np.exp((logits[b] - m).astype(F32)).astype(F32)
+        e = det_expf((logits[b] - m).astype(F32))
         pre = np.zeros(nthreads + 1, F32)
         c = F32(0)
         for t in range(nthreads):
@@ -336,16 +353,26 @@ def sample_inverse_cdf(logits, u, nthreads=256):
     return out
 
 
-def philox_uniform(seed, clip_index, position):
-    """Philox4x32-10, counter (position, clip_lo, clip_hi, 0), key (seed_lo, seed_hi); u = (word0 >> 8) * 2^-24."""
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123's philox4x32_R(10, ...)):
+    4 counter words, 2 key words -> 4 output words.  Restated from the publication (the reference draws with torch's generator;
+    this is the stream the HIP sampler uses instead, `csrc/vq.hip::philox4x32_10`); pinned to Random123's known-answer vectors
+    by `tests/test_sampling_oracle.py`."""
     M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
-    c = [position & 0xFFFFFFFF, clip_index & 0xFFFFFFFF, (clip_index >> 32) & 0xFFFFFFFF, 0]
-    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    c = [int(v) & 0xFFFFFFFF for v in counter]
+    k0, k1 = int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF
     for _ in range(10):
         p0, p1 = M0 * c[0], M1 * c[2]
         c = [((p1 >> 32) ^ c[1] ^ k0) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k1) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
         k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
-    return np.float32((c[0] >> 8) * (1.0 / 16777216.0))
+    return c
+
+
+def philox_uniform(seed, clip_index, position):
+    """The sampler's uniform: counter (position, clip_lo, clip_hi, 0), key (seed_lo, seed_hi); u = (word0 >> 8) * 2^-24."""
+    w = philox4x32_10([position, clip_index & 0xFFFFFFFF, (clip_index >> 32) & 0xFFFFFFFF, 0],
+                      [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF])
+    return np.float32((w[0] >> 8) * (1.0 / 16777216.0))
 
 
 def philox_uniforms(seed, clip_index0, B, H):

@@ -74,6 +74,7 @@ SIGNATURES = {
     "ts_op_vq_argmin": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "ts_op_linear": (_i, [_vp, _vp, _i, _i, _fp, _fp, _i, _i, _vp, _vp]),
     "ts_op_sample": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ts_op_sample_philox": (_i, [_vp, _vp, _i, _i, _u64, _i64, C.c_uint32, _vp, _vp]),
     "ts_debug_skinny_chain": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_float)]),
     "ts_smplx_create": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, C.POINTER(C.c_int32), _fp, _fp, C.POINTER(C.c_int32), _i,
                              C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32), _fp, _i, C.POINTER(_vp)]),

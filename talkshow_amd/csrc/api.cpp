@@ -333,4 +333,28 @@ int ts_op_sample(ts_ctx *ctx, const float *logits, int B, int V, int mode, const
     return 0;
 }
 
+int ts_op_sample_philox(ts_ctx *ctx, const float *logits, int B, int V, uint64_t seed, int64_t clip_index0, uint32_t position,
+                        int64_t *idx, void *stream) {
+    if (!ctx || !logits || !idx) return fail("ts_op_sample_philox: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf tok;
+    TS_TRY(tok.ensure((size_t)B * sizeof(int)));
+    SampleParams sp;
+    std::memset(&sp, 0, sizeof(sp));
+    sp.logits = logits;
+    sp.B = B;
+    sp.V = V;
+    sp.mode = TS_SAMPLE_PHILOX;
+    sp.seed = seed;
+    sp.clip_index0 = clip_index0;
+    sp.position = position;
+    sp.tok32 = tok.i();
+    sp.tok_stride = 1;
+    sp.codes = idx;
+    sp.code_stride = 1;
+    TS_HIP(launch_sample(sp, s));
+    TS_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
 }  // extern "C"

@@ -164,6 +164,28 @@ hipError_t launch_i64_to_i32(const int64_t *src, int *dst, long n, hipStream_t s
 // measurement aid: n records of (wall ticks since start, wall ticks of the window, shader cycles of the window), 100 MHz wall clock
 hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long long window_ticks, hipStream_t stream);
 
+// exp(x) for x <= 0 from fp32 multiplies and adds ONLY (no fused multiply-add, no hardware transcendental): every operation is
+// one IEEE round-to-nearest fp32 operation, so `oracle/talkshow_oracle.py::det_expf` reproduces it bit for bit on any host and
+// the inverse-CDF draw of a given uniform is the same index on the device and in the oracle — not "within one slot".
+// Cody-Waite reduction by ln 2 (n * LN2_HI is exact), degree-5 polynomial on [-ln2/2, ln2/2] (Cephes' coefficients), 2^n by
+// exponent bits; relative error < 2 ulp.  Arguments below -86 give 0 (2^-124: everything stays a normal number).
+__device__ inline float det_expf(float x) {
+#pragma clang fp contract(off)
+    if (x < -86.0f) return 0.0f;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = x - n * 0.693145751953125f;
+    r = r - n * 1.42860682030941723212e-6f;
+    float q = 1.9875691500e-4f;
+    q = q * r + 1.3981999507e-3f;
+    q = q * r + 8.3334519073e-3f;
+    q = q * r + 4.1665795894e-2f;
+    q = q * r + 1.6666665459e-1f;
+    q = q * r + 5.0000001201e-1f;
+    float y = q * (r * r) + r;
+    y = y + 1.0f;
+    return y * __int_as_float(((int)n + 127) << 23);
+}
+
 struct SampleParams {
     const float *logits;   // [B][V]
     int B, V;

@@ -137,9 +137,9 @@ __device__ __forceinline__ void chain_sample_clip(const SampleParams &p, const i
         if (act) {
             if (fast) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s += expf(x[k] - best);
+                for (int k = 0; k < 8; ++k) s += det_expf(x[k] - best);
             } else {
-                for (int v = v0; v < v1; ++v) s += expf(lg[v] - best);
+                for (int v = v0; v < v1; ++v) s += det_expf(lg[v] - best);
             }
             sf[tid + 1] = s;
         }
@@ -160,12 +160,12 @@ __device__ __forceinline__ void chain_sample_clip(const SampleParams &p, const i
                 bool found = false;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    c += expf(x[j] - best);
+                    c += det_expf(x[j] - best);
                     if (!found && c > thr) { k = v0 + j; found = true; }
                 }
             } else {
                 for (int v = v0; v < v1; ++v) {
-                    c += expf(lg[v] - best);
+                    c += det_expf(lg[v] - best);
                     if (c > thr) { k = v; break; }
                 }
             }

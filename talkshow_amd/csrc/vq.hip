@@ -252,7 +252,8 @@ hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long lon
 //   sampling : inverse CDF of softmax(logits).  p_v ∝ exp(l_v - max); thread t owns the contiguous chunk
 //              [t*V/256, (t+1)*V/256), sums it left to right; thread 0 prefix-sums the 256 chunk sums left to right;
 //              the draw is the first index whose running sum exceeds u * total.  oracle/talkshow_oracle.py
-//              (`sample_inverse_cdf`) restates exactly this summation structure, so draws are comparable bit for bit.
+//              (`sample_inverse_cdf`) restates exactly this summation structure AND the exponential (`det_expf` below: fp32
+//              multiplies / adds only), so the draw of a given uniform is the same index bit for bit.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                      uint32_t &o0) {
@@ -344,9 +345,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
         float s = 0.f;
         if (fast) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s += expf(x[k] - best);
+            for (int k = 0; k < 8; ++k) s += det_expf(x[k] - best);
         } else {
-            for (int v = v0; v < v1; ++v) s += expf(lg[v] - best);
+            for (int v = v0; v < v1; ++v) s += det_expf(lg[v] - best);
         }
         sf[tid + 1] = s;
         __syncthreads();
@@ -367,12 +368,12 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
                 bool found = false;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {   // same running sum as the loop below; the first crossing is latched
-                    c += expf(x[j] - best);
+                    c += det_expf(x[j] - best);
                     if (!found && c > thr) { k = v0 + j; found = true; }
                 }
             } else {
                 for (int v = v0; v < v1; ++v) {
-                    c += expf(lg[v] - best);
+                    c += det_expf(lg[v] - best);
                     if (c > thr) { k = v; break; }
                 }
             }

@@ -247,7 +247,18 @@ def get_mfcc_ta(aud_fn, eps=1e-6, fps=15, smlpx=False, sr=16000, n_mfcc=64, win_
     """`get_mfcc_ta` (`utils.py:148-231`), body branch: -> (T, 64) float32 features.
 
     wav files: resample + MFCC run on the GPU (ts_mfcc_forward) when a HIP device is present, else on the host in numpy
-    (`host=True` forces the numpy path, which is also the checker of the device path in tests/)."""
+    (`host=True` forces the numpy path, which is also the checker of the device path in tests/).  With a processor handed in
+    (`am is not None`) the reference switches on `encoder_choice` (`utils.py:193-202`): 'faceformer' -> `get_wav16`,
+    'meshtalk' -> scaled samples, 'onset' -> NotImplementedError here, anything else -> the MFCC features as without `am`."""
+    if am is not None and encoder_choice in ('faceformer', 'meshtalk', 'onset'):
+        # the reference's `am is not None` branch (`utils.py:193-202`): librosa.load(sr=16000), then a switch on encoder_choice
+        if encoder_choice == 'faceformer':                      # raw 16 kHz samples (N, 1): the face generator's input
+            return get_wav16(aud_fn, host=host)
+        if encoder_choice == 'meshtalk':                        # `0.01 * speech_array / np.mean(np.abs(speech_array))`, shape (N,)
+            x = get_wav16(aud_fn, host=host)[:, 0]
+            return (F32(0.01) * x / np.mean(np.abs(x))).astype(F32)
+        raise NotImplementedError("encoder_choice='onset' needs librosa.onset.onset_detect (third-party, absent; no shipped "
+                                  "config uses it)")
     feat = _features_from_any(aud_fn)
     if feat is None:
         if type != 'mfcc':

@@ -223,6 +223,15 @@ class VQVAE(NativeModule):
                                                _lib.stream_ptr()))
         return out
 
+    def decode_z_nlc(self, z):
+        """Decoder.forward on CONTINUOUS latents z (B,H,embedding_dim) -> (B,4H,in_dim) (`ts_vqvae_decode_z`)."""
+        z = _dev_f32(z, self._dev())
+        B, H, _ = z.shape
+        out = torch.empty((B, 4 * H, self.in_dim), dtype=torch.float32, device=z.device)
+        _lib.check(_lib.load().ts_vqvae_decode_z(self.handle(), _lib.dptr(z), B, H, _lib.dptr(out), self.in_dim, 0,
+                                                 _lib.stream_ptr()))
+        return out
+
     def forward_nlc(self, poses, out=None, col0=0):
         poses = _dev_f32(poses, self._dev())
         B, T, _ = poses.shape
@@ -242,8 +251,9 @@ class VQVAE(NativeModule):
 
     def decode(self, b, w, e=None, latents=None, pre_state=None):
         """`VQVAE.decode` (`vqvae_1d.py:201-208`): returns the reference's tuple (recon (B,in_dim,4w), None)."""
-        if e is not None:
-            raise NotImplementedError("decode(e=...) (continuous latents) is not on the inference path; pass latents=")
+        if e is not None:      # continuous latents (B, embedding_dim, w): Decoder.forward on them as they are (`vqvae_1d.py:202-203`)
+            z = _dev_f32(e, self._dev()).transpose(1, 2).contiguous()
+            return self.decode_z_nlc(z).transpose(1, 2), None
         return self.decode_nlc(latents.reshape(b, w)).transpose(1, 2), None
 
     def __call__(self, gt_poses, id=None, pre_state=None):
@@ -271,14 +281,6 @@ class AE(VQVAE):
         _lib.check(_lib.load().ts_vqvae_encode(self.handle(), _lib.dptr(poses), B, T, _lib.dptr(z), None, None,
                                                _lib.stream_ptr()))
         return z
-
-    def decode_z_nlc(self, z):
-        z = _dev_f32(z, self._dev())
-        B, H, _ = z.shape
-        out = torch.empty((B, 4 * H, self.in_dim), dtype=torch.float32, device=z.device)
-        _lib.check(_lib.load().ts_vqvae_decode_z(self.handle(), _lib.dptr(z), B, H, _lib.dptr(out), self.in_dim, 0,
-                                                 _lib.stream_ptr()))
-        return out
 
     # --- reference call shapes ---
     def encode(self, gt_poses, id=None):

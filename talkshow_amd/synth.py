@@ -90,8 +90,13 @@ def audioencoder_state_dict(seed=0, in_dim=64, num_hiddens=256, num_residual_lay
 
 
 def vqvae_state_dict(seed=0, in_dim=39, embedding_dim=64, num_embeddings=2048, num_hiddens=1024,
-                     num_residual_layers=2, salt=0, in_scale=0.3, out_scale=0.3):
-    """`VQVAE(in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers, ·)` (`vqvae_1d.py:152-208`)."""
+                     num_residual_layers=2, salt=0, in_scale=0.3, out_scale=0.3, codebook=None):
+    """`VQVAE(in_dim, embedding_dim, num_embeddings, num_hiddens, num_residual_layers, ·)` (`vqvae_1d.py:152-208`).
+
+    `codebook=(mu, sigma)` (two `(embedding_dim,)` float32 arrays) re-draws `vq_layer.embeddings` as `mu + sigma * N(0, 1)`
+    per channel — elementwise float32 arithmetic only, so every machine gets the same bits — for fixtures that want the
+    encoder's outputs to land on many different entries (`tests/golden/make_golden.py::vq_encode_b32`); everything else in
+    the dict is unchanged by it."""
     b = _Builder(seed, 202 + salt)
     hid = num_hiddens
     _encoder_like(b, "encoder.", in_dim, hid, num_residual_layers, 1.0 / in_scale)
@@ -106,6 +111,10 @@ def vqvae_state_dict(seed=0, in_dim=39, embedding_dim=64, num_embeddings=2048, n
     b.cnr("decoder._up_3", hid // 2, hid // 4, sample="up", residual=True)
     b.stack("decoder._dec_3", hid // 4, num_residual_layers)
     b.conv("decoder.project", in_dim, hid // 4, 1, out_scale)
+    if codebook is not None:
+        mu, sigma = (np.asarray(v, F32).reshape(1, embedding_dim) for v in codebook)
+        g = _rng(seed, 909 + salt).standard_normal((num_embeddings, embedding_dim)).astype(F32)
+        b.sd["vq_layer.embeddings"] = (mu + sigma * g).astype(F32)
     return b.sd
 
 

@@ -234,6 +234,68 @@ def main():
             save("body_vq_e2e_full", poses129=p129, out=out, codes=np.stack([lat_b.numpy(), lat_h.numpy()], -1),
                  c_index=np.asarray(c_index_3d))
 
+    # ---- 4b. BASELINE operating point: the greedy harness on a whole batch of 32 ten-second clips (4 800 decisions) ------------
+    # (every batch test embedded the same two body_e2e_full clips.)  ~2-4 min on 8 cores.
+    if args.only == "body_e2e_b32" or (not args.only and os.environ.get("TS_GOLDEN_BIG")):
+        tmp = tempfile.mkdtemp(prefix="ts_golden_")
+        vq_path = os.path.join(tmp, "vq.pth")
+        torch.save({"generator": {"g_body": T(synth.vqvae_state_dict(seed=7, in_dim=39)),
+                                  "g_hand": T(synth.vqvae_state_dict(seed=7, in_dim=90, salt=1))}}, vq_path)
+        cfg = json.load(open(os.path.join(REF, "config/body_pixel.json")))
+        cfg["Model"]["vq_path"] = vq_path
+        from trainer.config import Object
+        w = quiet(nets.s2g_body_pixel, argparse.Namespace(gpu="cpu", infer=True), Object(cfg))
+        w.load_state_dict({"generator": T(synth.pixelcnn_state_dict(seed=7)), "audioencoder": T(synth.audioencoder_state_dict(seed=7))})
+        B, Tn, mf_seed = 32, 300, 23
+        mf, ids = synth.mfcc_features(mf_seed, B, Tn), synth.speaker_ids(B)
+        w.generator.eval(); w.g_body.eval(); w.g_hand.eval(); w.audioencoder.eval()
+        with torch.no_grad():
+            feat = w.audioencoder(torch.from_numpy(mf).transpose(1, 2), frame_num=0)
+            aud = feat.unsqueeze(-1).repeat(1, 1, 1, 2)
+            H = aud.shape[2]
+            codes, step_logits = greedy_reference(w.generator, torch.from_numpy(ids), aud, H)
+            keep = np.asarray([0, 9, 18, 31])
+            body, _ = w.g_body.decode(b=len(keep), w=H, latents=codes[keep][..., 0])
+            hand, _ = w.g_hand.decode(b=len(keep), w=H, latents=codes[keep][..., 1])
+            poses = torch.cat([body, hand], dim=1).transpose(1, 2)
+        m = margins(step_logits.numpy()).reshape(B, H, 2)
+        print("body_e2e_b32: margin min/median", float(m.min()), float(np.median(m)), "uniq codes", codes.unique().numel(),
+              "decisions under 1e-3:", int((m < 1e-3).sum()))
+        save("body_e2e_b32", mfcc_seed=np.asarray([mf_seed, B, Tn]), ids=ids, codes=codes.numpy().astype(np.int16),
+             margin=m.astype(np.float32), pose_clips=keep, poses=poses.numpy())
+
+    # ---- 4c. the VQ-encode half of configs[1] at its operating point: 32 clips x 300 GT frames through the reference's
+    # VQVAE.encode (vqvae_1d.py:196-199 -> vqvae_modules.py:274-286,311-319), body and hand, with a codebook that the encoder's
+    # outputs actually SPREAD over: the default synthetic codebook attracts 9 / 30 of 2 048 entries, so the
+    # entries are re-drawn around the per-channel mean / spread of z (`synth.vqvae_state_dict(codebook=(mu, sigma))`, stored here)
+    if want("vq_encode_b32"):
+        B, Tn, gt_seed = 32, 300, 24
+        p129 = synth.gt_poses(gt_seed, B, Tn)
+        out = {}
+        for part, in_dim, salt, sl in (("body", 39, 0, slice(0, 39)), ("hand", 90, 1, slice(39, 129))):
+            x = torch.from_numpy(np.ascontiguousarray(p129[..., sl]))
+            net = VQVAE(in_dim, 64, 2048, 1024, 2, 512)
+            net.load_state_dict(T(synth.vqvae_state_dict(seed=7, in_dim=in_dim, salt=salt)), strict=True)
+            net.eval()
+            with torch.no_grad():
+                z = net.encoder(x.transpose(1, 2)).permute(0, 2, 1).reshape(-1, 64).numpy().astype(np.float64)
+            mu, sigma = z.mean(0).astype(np.float32), z.std(0).astype(np.float32)
+            sd = synth.vqvae_state_dict(seed=7, in_dim=in_dim, salt=salt, codebook=(mu, sigma))
+            net.load_state_dict(T(sd), strict=True)
+            with torch.no_grad():
+                e, lat = net.encode(gt_poses=x)                                  # what bench.py's encode half computes
+                zt = net.encoder(x.transpose(1, 2)).permute(0, 2, 1).reshape(-1, 64)
+                d = ((zt ** 2).sum(1, keepdim=True) + (net.vq_layer.embeddings ** 2).sum(1)
+                     - 2.0 * zt @ net.vq_layer.embeddings.t())                  # get_code_indices' own expression
+                top2 = torch.topk(d, 2, dim=1, largest=False).values
+                assert torch.equal(d.argmin(1).view(B, -1), lat)
+                rec, _ = net.decode(b=2, w=lat.shape[1], latents=lat[:2])
+            mg = (top2[:, 1] - top2[:, 0]).view(B, -1).numpy()
+            print(f"vq_encode_b32 {part}: distinct codes {lat.unique().numel()} margin min/median {mg.min():.2e} {np.median(mg):.3f}")
+            out.update({f"mu_{part}": mu, f"sigma_{part}": sigma, f"codes_{part}": lat.numpy().astype(np.int16),
+                        f"margin_{part}": mg.astype(np.float32), f"recon2_{part}": rec.numpy()})
+        save("vq_encode_b32", gt_seed=np.asarray([gt_seed, B, Tn]), **out)
+
     # ---- 5. face generator over the installed transformers wav2vec2 (reference: s2g_face.Generator + wav2vec.py) ----
     if want("face_full"):
         fcfg = json.load(open(os.path.join(REF, "config/face.json")))

@@ -1,0 +1,117 @@
+"""bench.py's N > 1 control flow without a GPU: `run_contract` + `finish` driven under gloo at world 1 / 2 / 3 with
+a device-free stand-in of `BodyJob`.  What must hold for the driver's 8-GPU run to be readable:
+
+* every rank times exactly `steps` steps after `warmup` untimed ones, the exchange runs once untimed and once inside the bracket;
+* the reported time is the MAX over ranks (the slow rank's), value = all ranks' frames / that time;
+* only rank 0 emits a line, only rank 0 runs the extra measurement legs, and it runs them AFTER the process group is gone — no
+  rank sits in a collective while rank 0 measures;
+* every rank checks what it timed (selfcheck) before leaving.
+"""
+import json
+import os
+import socket
+import time
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class StubJob:
+    """Same methods as bench.BodyJob; a step is a sleep whose length depends on the rank, rows are the global clip numbers."""
+
+    def __init__(self, world, rank, log):
+        self.world, self.rank, self.log, self.steps_run = world, rank, log, []
+        self.rows = None
+
+    def _say(self, what):
+        with open(self.log, "a") as f:
+            f.write(json.dumps({"rank": self.rank, "what": what, "t": time.perf_counter(),
+                                "group_alive": dist.is_initialized()}) + "\n")
+
+    def warm(self, steps):
+        self._say(f"warm {steps}")
+
+    def run_steps(self, k):
+        self._say(f"run_steps {k}")
+        time.sleep(0.01 * k * (1 + self.rank))                  # rank r is (1 + r) times slower: the max is the last rank's
+        clip0 = self.rank * k * 4
+        self.rows = torch.arange(clip0, clip0 + k * 4, dtype=torch.float32).view(-1, 1, 1) * torch.ones(1, 3, 2)
+
+    def sync(self):
+        pass
+
+    def scalar(self, x):
+        return torch.tensor([x], dtype=torch.float64)
+
+    def gather(self):
+        from talkshow_amd.parallel import gather_sequences
+        self._say("gather")
+        allp = gather_sequences(self.rows)
+        assert torch.equal(allp[:, 0, 0], torch.arange(allp.shape[0], dtype=torch.float32))      # clip k lands at row k
+        return {"gather_bytes_per_rank": int(self.rows.numel() * 4), "gathered_shape": list(allp.shape)}
+
+    def frames_per_step(self):
+        return 4 * 300
+
+    def describe(self):
+        return {"workload": "stub"}
+
+    def selfcheck(self):
+        self._say("selfcheck")
+        return {"selfcheck": "ok"}
+
+    def extras(self, out):
+        self._say("extras")
+        time.sleep(0.05)                                         # long enough that a rank waiting in a collective would show
+        out["roofline"] = {"frac": 0.0}
+
+
+def _worker(rank, world, port, steps, warmup, tmp):
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    job = StubJob(world, rank, os.path.join(tmp, f"log{rank}.jsonl"))
+    dt, t_compute, info = bench.run_contract(job, dist, world, rank, steps, warmup)
+    lines = []
+    bench.finish(job, dist, world, rank, steps, warmup, dt, info, emit=lines.append)
+    with open(os.path.join(tmp, f"out{rank}.json"), "w") as f:
+        json.dump({"lines": lines, "dt": dt, "t_compute": t_compute, "end": time.perf_counter(),
+                   "group_alive_at_exit": dist.is_initialized()}, f)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_bench_contract_control_flow(tmp_path, world):
+    steps, warmup = 5, 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(world, port, steps, warmup, str(tmp_path)), nprocs=world, join=True)
+    outs = [json.load(open(tmp_path / f"out{r}.json")) for r in range(world)]
+    logs = [[json.loads(l) for l in open(tmp_path / f"log{r}.jsonl")] for r in range(world)]
+    # one JSON line, from rank 0 only
+    assert len(outs[0]["lines"]) == 1 and all(o["lines"] == [] for o in outs[1:])
+    line = json.loads(outs[0]["lines"][0])
+    assert line["n_gpus"] == world and line["steps"] == steps and line["warmup"] == warmup and line["selfcheck"] == "ok"
+    assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["vs_baseline"] is None
+    # max over ranks: every rank reports the same time, at least the slowest rank's compute time
+    assert len({round(o["dt"], 9) for o in outs}) == 1
+    assert outs[0]["dt"] >= max(o["t_compute"] for o in outs) and outs[0]["dt"] >= 0.01 * steps * world
+    assert abs(line["value"] - world * steps * 4 * 300 / outs[0]["dt"]) < 1e-6 * line["value"]
+    assert abs(line["ms_per_step"] - outs[0]["dt"] / steps * 1e3) < 1e-9
+    if world > 1:
+        assert line["rccl"]["ranks_seen"] == world and line["rccl"]["gathered_shape"] == [world * steps * 4, 3, 2]
+    else:
+        assert line["rccl"] is None
+    for r, log in enumerate(logs):
+        what = [e["what"] for e in log]
+        want = [f"warm {steps}", f"run_steps {warmup}"] + (["gather"] if world > 1 else []) + [f"run_steps {steps}"] \
+            + (["gather"] if world > 1 else []) + ["selfcheck"] + (["extras"] if r == 0 else [])
+        assert what == want, (r, what)
+        assert not outs[r]["group_alive_at_exit"]
+    # rank 0's extras run with no process group alive, and no other rank waits for them: the others are done before they end
+    ex = [e for e in logs[0] if e["what"] == "extras"][0]
+    assert ex["group_alive"] is False
+    for r in range(1, world):
+        assert outs[r]["end"] < outs[0]["end"] - 0.04, "a rank other than 0 was still around while rank 0 ran its extras"

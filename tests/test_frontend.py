@@ -175,6 +175,27 @@ def test_get_wav16_resamples_other_rates(tmp_path):
     assert np.abs(w[400:-400, 0] - ref[400:-400]).max() < 2e-3
 
 
+def test_get_mfcc_ta_encoder_choice_switch(tmp_path):
+    """`get_mfcc_ta(am=<processor>, encoder_choice=...)` (`data_utils/utils.py:193-202`): 'faceformer' -> the raw 16 kHz samples
+    (N, 1), 'meshtalk' -> samples scaled to mean |x| = 0.01, 'onset' -> refused by name (librosa.onset is absent), any other
+    value -> the MFCC features exactly as without `am`; without `am` the argument has no effect, as in the reference."""
+    from scipy.io import wavfile
+    x = (0.2 * np.sin(2 * np.pi * 250 * np.arange(16000) / 16000.0)).astype(np.float32)
+    p = str(tmp_path / "b.wav")
+    wavfile.write(p, 16000, x)
+    am = object()
+    w = fe.get_mfcc_ta(p, sr=16000, fps=30, am=am, encoder_choice='faceformer', host=True)
+    assert w.shape == (16000, 1) and np.array_equal(w[:, 0], x)
+    m = fe.get_mfcc_ta(p, sr=16000, fps=30, am=am, encoder_choice='meshtalk', host=True)
+    assert m.shape == (16000,) and abs(float(np.mean(np.abs(m))) - 0.01) < 1e-6
+    with pytest.raises(NotImplementedError, match="onset"):
+        fe.get_mfcc_ta(p, sr=16000, fps=30, am=am, encoder_choice='onset', host=True)
+    base = fe.get_mfcc_ta(p, sr=22000, fps=30, host=True)
+    assert base.shape[1] == 64
+    for kw in (dict(am=am), dict(am=am, encoder_choice='mfcc'), dict(encoder_choice='faceformer')):
+        assert np.array_equal(fe.get_mfcc_ta(p, sr=22000, fps=30, host=True, **kw), base)
+
+
 @pytest.mark.parametrize("orig,new,n", [(16000, 22000, 1601), (22000, 16000, 2203), (48000, 16000, 4000), (8000, 22050, 333)])
 def test_sinc_hann_resampler_against_its_continuous_definition(orig, new, n):
     """The polyphase / strided-window implementation (what torchaudio does, and what the device kernel mirrors) against the

@@ -1,0 +1,216 @@
+"""Parity at the operating points bench.py actually runs, all through the C ABI.
+
+* the VQ-encode half of configs[1] in the form the bench calls it — `ts_body_vq_infer(n = 32 / 256 clips, recon = NULL)`, body and
+  hand in lockstep, banded conv launches — against codes the reference's `VQVAE.encode` produced (`vqvae_1d.py:196-199`,
+  `vqvae_modules.py:311-319`): the two `body_vq_e2e_full` clips at arbitrary slots, and a whole batch of 32 clips whose 4 800
+  nearest-neighbour decisions spread over 752 / 845 codebook entries (`vq_encode_b32`);
+* greedy decode of a whole BASELINE batch — 32 clips x 75 x 2 = 4 800 decisions of the reference harness (`body_e2e_b32`) —
+  alone and inside the bench's 256-clip pass;
+* configs[3] at full size: injected uniforms on the 2 048 / 256 / 15 network against the oracle's full-grid generate, every draw
+  re-derived from the device's own logits with the oracle's inverse CDF (exact: the sampler's exponential is fp32 mul / add only),
+  and a chi-square of 204 800 Philox draws against the softmax of a real 2 048-logit row.
+
+Counting rule for index outputs compared with the CPU reference: a decision whose reference top-2 margin is below NEAR_TIE may
+legitimately flip under a different fp32 summation order; everything else must be equal.  The tests print
+`equal / total` so the count can be quoted.
+"""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import talkshow_oracle as O
+from talkshow_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NEAR_TIE_LOGIT = 1e-3      # greedy: logits agree with the reference to <= 3e-4 (test_pixelcnn_golden), so 1e-3 of margin decides
+NEAR_TIE_DIST = 5e-4       # VQ search: z agrees to <= 2e-5 and |e_a - e_b| ~ 3, so distances move by ~1e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from talkshow_amd import _lib
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return _lib, _lib.load(), _lib.context(0)
+
+
+def _vq_pair(codebook_body=None, codebook_hand=None):
+    from talkshow_amd.modules import VQVAE
+    vb, vh = VQVAE(39, 64, 2048, 1024, 2).cuda(), VQVAE(90, 64, 2048, 1024, 2).cuda()
+    vb.load_state_dict(synth.to_torch(synth.vqvae_state_dict(seed=7, in_dim=39, codebook=codebook_body)))
+    vh.load_state_dict(synth.to_torch(synth.vqvae_state_dict(seed=7, in_dim=90, salt=1, codebook=codebook_hand)))
+    return vb, vh
+
+
+def _encode(hip, vb, vh, poses, with_recon):
+    """exactly bench.py's call: ts_body_vq_infer(g_body, g_hand, poses (n,300,129), n, 300, codes, recon or NULL)."""
+    _lib, lib, _ = hip
+    n, T = poses.shape[:2]
+    codes = torch.full((n, T // 4, 2), -1, dtype=torch.int64, device="cuda")
+    recon = torch.empty((n, T, 129), dtype=torch.float32, device="cuda") if with_recon else None
+    _lib.check(lib.ts_body_vq_infer(vb.handle(), vh.handle(), _lib.dptr(poses), n, T, _lib.dptr(codes), _lib.dptr(recon),
+                                    _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return codes.cpu().numpy(), (recon.cpu().numpy() if with_recon else None)
+
+
+def test_vq_encode_only_form_at_bench_sizes(hip, golden):
+    """The two reference-golden clips of `body_vq_e2e_full` at arbitrary slots of a 32- and a 256-clip encode-only call
+    (recon = NULL: the form bench.py times) — codes bit-equal to the golden and to the recon != NULL form of the same call;
+    the reconstruction of the golden clips stays within 1e-4 of the reference wrapper's output."""
+    g = golden("body_vq_e2e_full")
+    vb, vh = _vq_pair()
+    for n, slots in ((32, (5, 30)), (256, (131, 255))):
+        poses = synth.gt_poses(700 + n, n, 300)
+        for k, s_ in enumerate(slots):
+            poses[s_] = g["poses129"][k]
+        pd = torch.from_numpy(poses).cuda()
+        c_enc, _ = _encode(hip, vb, vh, pd, with_recon=False)
+        c_full, recon = _encode(hip, vb, vh, pd, with_recon=True)
+        assert (c_enc >= 0).all() and (c_enc < 2048).all()
+        np.testing.assert_array_equal(c_enc, c_full)                       # encode-only == encode + decode, every clip
+        for k, s_ in enumerate(slots):
+            np.testing.assert_array_equal(c_enc[s_], g["codes"][k])        # == reference VQVAE.encode
+            ref = g["out"][:, k * 129:(k + 1) * 129]                       # wrapper output: (T, B*129), clip-major columns
+            np.testing.assert_allclose(recon[s_], ref, atol=1e-4, rtol=0)
+
+
+def test_vq_encode_b32_golden_counts(hip, golden):
+    """A whole BASELINE batch through the encode-only call against the reference's `VQVAE.encode`: 2 x 2 400 nearest-neighbour
+    decisions over a codebook the encoder's outputs spread on (752 body / 845 hand distinct entries of 2 048), alone and as
+    clips 96..127 of the bench's 256-clip pass."""
+    g = golden("vq_encode_b32")
+    seed, B, T = (int(v) for v in g["gt_seed"])
+    vb, vh = _vq_pair((g["mu_body"], g["sigma_body"]), (g["mu_hand"], g["sigma_hand"]))
+    p129 = synth.gt_poses(seed, B, T)
+    ref = np.stack([g["codes_body"], g["codes_hand"]], -1).astype(np.int64)          # (32, 75, 2)
+    margin = np.stack([g["margin_body"], g["margin_hand"]], -1)
+    assert len(np.unique(g["codes_body"])) >= 500 and len(np.unique(g["codes_hand"])) >= 500
+    got32, _ = _encode(hip, vb, vh, torch.from_numpy(p129).cuda(), with_recon=False)
+    big = synth.gt_poses(seed + 1, 256, T)
+    big[96:128] = p129
+    got256, recon = _encode(hip, vb, vh, torch.from_numpy(big).cuda(), with_recon=True)
+    np.testing.assert_array_equal(got256[96:128], got32)                  # a clip's codes do not depend on the pass it rides in
+    diff = got32 != ref
+    print(f"\nvq_encode_b32: codes equal to the reference {int((~diff).sum())} / {diff.size}"
+          + (f"; margins at the differences {np.sort(margin[diff])[:5]}" if diff.any() else ""))
+    assert (margin[diff] < NEAR_TIE_DIST).all(), f"a decision with margin {margin[diff].max():.2e} differs from the reference"
+    assert diff.sum() <= 4
+    # the reference's reconstruction of clips 0 and 1 (VQVAE.decode of the reference codes)
+    for k in range(2):
+        if not diff[k].any():
+            rec = np.concatenate([g["recon2_body"][k].T, g["recon2_hand"][k].T], 1)   # (300, 129)
+            np.testing.assert_allclose(recon[96 + k], rec, atol=1e-4, rtol=0)
+
+
+def _body_wrapper(tmp_path):
+    from nets.init_model import init_model
+    from talkshow_amd.config import Object
+    vq_path = str(tmp_path / "vq.pth")
+    torch.save({"generator": {"g_body": synth.to_torch(synth.vqvae_state_dict(seed=7, in_dim=39)),
+                              "g_hand": synth.to_torch(synth.vqvae_state_dict(seed=7, in_dim=90, salt=1))}}, vq_path)
+    cfg = json.load(open(os.path.join(REPO, "config", "body_pixel.json")))
+    cfg["Model"]["vq_path"] = vq_path
+    w = init_model("s2g_body_pixel", argparse.Namespace(gpu=0, infer=True), Object(cfg))
+    w.load_state_dict({"generator": synth.to_torch(synth.pixelcnn_state_dict(seed=7)),
+                       "audioencoder": synth.to_torch(synth.audioencoder_state_dict(seed=7))})
+    return w
+
+
+def test_greedy_b32_golden_counts(hip, golden, tmp_path):
+    """32 clips x 75 x 2 = 4 800 greedy decisions of the reference harness (`body_e2e_b32`: reference `GatedPixelCNN.forward`
+    driven position by position over the whole batch) against one BASELINE batch and against the same clips inside the bench's
+    256-clip pass (wide kernel).  Decoding is autoregressive, so a clip is compared up to its first difference, which must sit
+    on a reference near-tie; poses of the stored clips within 1e-4."""
+    _lib = hip[0]
+    g = golden("body_e2e_b32")
+    seed, B, T = (int(v) for v in g["mfcc_seed"])
+    w = _body_wrapper(tmp_path)
+    mf, ids = synth.mfcc_features(seed, B, T), g["ids"]
+    ref, margin = g["codes"].astype(np.int64), g["margin"]
+    c32, p32 = w.generate_batch(mf, ids, mode=_lib.TS_SAMPLE_GREEDY)
+    big, big_ids = synth.mfcc_features(seed + 1, 256, T), synth.speaker_ids(256)
+    big[160:192], big_ids[160:192] = mf, ids
+    c256, p256 = w.generate_batch(big, big_ids, mode=_lib.TS_SAMPLE_GREEDY)
+    c32, c256 = c32.cpu().numpy(), c256.cpu().numpy()[160:192]
+    np.testing.assert_array_equal(c256, c32)
+    np.testing.assert_array_equal(p256[160:192].cpu().numpy(), p32.cpu().numpy())
+    equal = 0
+    for b in range(B):
+        d = np.flatnonzero((c32[b] != ref[b]).reshape(-1))
+        if d.size == 0:
+            equal += ref[b].size
+            continue
+        first = d[0]
+        equal += first
+        m = margin[b].reshape(-1)[first]
+        print(f"\nclip {b}: first difference at position {first}, reference top-2 margin {m:.2e}")
+        assert m < NEAR_TIE_LOGIT, f"clip {b} leaves the reference at a decision with margin {m:.2e}"
+    print(f"\nbody_e2e_b32: greedy codes equal to the reference {equal} / {ref.size} (margins: min {margin.min():.2e}, "
+          f"{int((margin < NEAR_TIE_LOGIT).sum())} under {NEAR_TIE_LOGIT})")
+    assert equal >= ref.size - 300                                       # at most two clips may leave at a near-tie
+    p32 = p32.cpu().numpy()
+    for k, b in enumerate(g["pose_clips"]):
+        if np.array_equal(c32[b], ref[b]):
+            np.testing.assert_allclose(p32[b], g["poses"][k], atol=1e-4, rtol=0)
+
+
+def test_full_size_sampling_vs_oracle(hip, golden):
+    """configs[3] at full size (2 048 classes, dim 256, 15 layers): decode driven by injected uniforms against the oracle's
+    full-grid `pixelcnn_generate(uniforms=...)` (`gated_pixelcnn_v2.py:167-176` with an inverse-CDF draw), the device Philox
+    stream against the oracle's, and EVERY draw re-derived from the device's own step logits with the oracle's
+    `sample_inverse_cdf` — exact, the exponential included."""
+    from talkshow_amd import _lib
+    from talkshow_amd.modules import GatedPixelCNN
+    g = golden("pix_full")
+    input_dim, dim, n_layers, n_cls, seed = [int(v) for v in g["cfg"]]
+    sd = synth.pixelcnn_state_dict(seed=seed, input_dim=input_dim, dim=dim, n_layers=n_layers, n_classes=n_cls)
+    m = GatedPixelCNN(input_dim, dim, n_layers, n_cls, True, True).cuda()
+    m.load_state_dict(synth.to_torch(sd))
+    B, H = g["codes"].shape[:2]
+    u = O.philox_uniforms(2024, 40, B, H)
+    got_u, lg = m.run(g["label"], g["aud"], mode=_lib.TS_SAMPLE_UNIFORMS, uniforms=u, want_logits=True)
+    got_p, _ = m.run(g["label"], g["aud"], mode=_lib.TS_SAMPLE_PHILOX, seed=2024, clip_index0=40)
+    got_u, lg = got_u.cpu().numpy(), lg.cpu().numpy()
+    np.testing.assert_array_equal(got_p.cpu().numpy(), got_u)                        # device Philox == oracle Philox
+    assert not np.array_equal(got_u, g["codes"])                                     # it does sample
+    redrawn = O.sample_inverse_cdf(lg.reshape(-1, input_dim), u.reshape(-1)).reshape(B, H, 2)
+    np.testing.assert_array_equal(got_u, redrawn)                                    # the sampler, exactly, on real logits
+    aud4 = np.repeat(g["aud"].transpose(0, 2, 1)[:, :, :, None], 2, axis=3)
+    ref = O.pixelcnn_generate(g["label"], aud4, sd, n_layers, H, uniforms=u)
+    np.testing.assert_array_equal(got_u, ref)
+
+
+def test_op_sample_philox_chi_square(hip, golden):
+    """204 800 device draws (Philox subsequences 0 .. 204 799 at one grid position) from ONE real 2 048-logit row (a step of the
+    full-size golden decode) against softmax of that row: Pearson chi-square over the classes with expected count >= 5 (the
+    rest pooled), p > 1e-3; and the draws are exactly the oracle's inverse CDF of the oracle's Philox uniforms."""
+    from scipy import stats
+    _lib, lib, ctx = hip
+    g = golden("pix_full")
+    row = np.ascontiguousarray(g["step_logits"][1, 7, 1])
+    V, nb, calls, pos, seed = row.size, 4096, 50, 15, 99
+    ld = torch.from_numpy(np.tile(row, (nb, 1))).cuda()
+    idx = torch.empty(nb, dtype=torch.int64, device="cuda")
+    draws = []
+    for c in range(calls):
+        _lib.check(lib.ts_op_sample_philox(ctx, _lib.dptr(ld), nb, V, seed, c * nb, pos, _lib.dptr(idx), None))
+        draws.append(idx.cpu().numpy().copy())
+    draws = np.concatenate(draws)
+    u = np.asarray([O.philox_uniform(seed, b, pos) for b in range(2048)], np.float32)
+    np.testing.assert_array_equal(draws[:2048], O.sample_inverse_cdf(np.tile(row, (2048, 1)), u))
+    p = np.exp(row.astype(np.float64) - row.max())
+    p /= p.sum()
+    n = draws.size
+    counts = np.bincount(draws, minlength=V).astype(np.float64)
+    big = p * n >= 5
+    obs = np.append(counts[big], counts[~big].sum())
+    exp = np.append(p[big] * n, p[~big].sum() * n)
+    chi2, pval = stats.chisquare(obs, exp)
+    print(f"\nchi-square over {big.sum()} classes + pooled rest, {n} draws: {chi2:.1f}, p = {pval:.3f}")
+    assert big.sum() >= 20 and pval > 1e-3

@@ -220,8 +220,9 @@ def test_op_sample(hip):
     _lib.check(lib.ts_op_sample(ctx, _lib.dptr(ld), B, V, _lib.TS_SAMPLE_UNIFORMS, _lib.dptr(ud), _lib.dptr(idx), None))
     ref = O.sample_inverse_cdf(logits, u)
     got = idx.cpu().numpy()
-    # expf on the device and np.exp on the host may differ in the last bit: allow a draw to move by one slot at a boundary
-    assert (np.abs(got - ref) <= 1).all() and (got != ref).sum() <= 1, (got, ref)
+    # exact: the oracle restates the kernel's summation order AND its exponential (det_expf: fp32 multiplies / adds only)
+    np.testing.assert_array_equal(got, ref)
+    assert got[0] == 0 or logits[0, :got[0]].max() < logits[0].max() - 86.0      # u = 0 -> the first class with any mass
 
 
 # ----------------------------------------------------------------------------------------------- modules vs golden
@@ -251,6 +252,12 @@ def test_vqvae_golden(hip, golden, name):
     rec2, none = m.decode(b=lat.shape[0], w=lat.shape[1], latents=lat)
     assert none is None
     np.testing.assert_array_equal(rec2.cpu().numpy(), x_recon.cpu().numpy())
+    # VQVAE.decode(e=...) (`vqvae_1d.py:201-203`): the decoder on given continuous latents — here the quantised ones, so the
+    # result is the reference's reconstruction again (the latents= path gathers rows of a table with aft_vq_conv pre-applied,
+    # this one multiplies: same values to rounding)
+    rec3, none = m.decode(b=lat.shape[0], w=lat.shape[1], e=torch.from_numpy(g["quantized"]))
+    assert none is None and rec3.shape == rec2.shape
+    np.testing.assert_allclose(rec3.cpu().numpy(), g["recon"], atol=1e-4, rtol=0)
 
 
 def test_audioenc_golden(hip, golden):
@@ -828,24 +835,25 @@ def test_device_mfcc_vs_host_restatement(hip, tmp_path):
         x22 = fe.resample_sinc_hann(w_[None], 16000, 22000)[0]
         ref = fe.mfcc(x22, 22000, hop_length=734).T
         assert dev[i].shape == ref.shape == (300 if len(x22) // 734 + 1 == 300 else len(x22) // 734 + 1, 64)
-        # coefficients are O(10..1000); fp32 DFT-as-GEMM vs pocketfft differ by summation order only
-        np.testing.assert_allclose(dev[i], ref, atol=0.05, rtol=2e-4)
+        # coefficients are O(10..200); fp32 DFT-as-GEMM vs pocketfft differ by summation order only: the device rows sit within
+        # 2e-4 of the float64 twin (test_wav_in_code_stability), the float32 twins within 2e-4 of it too; 2e-3 is the bound
+        np.testing.assert_allclose(dev[i], ref, atol=2e-3, rtol=2e-4)
     # no resampling branch + the wav-file entry point used by infer_on_audio
     x = (0.3 * rng.standard_normal(22000 * 2)).astype(np.float32)
     got22 = MFCC(22000, 22000, 30)(x)[0].cpu().numpy()
-    np.testing.assert_allclose(got22, fe.mfcc(x, 22000).T, atol=0.05, rtol=2e-4)
+    np.testing.assert_allclose(got22, fe.mfcc(x, 22000).T, atol=2e-3, rtol=2e-4)
     # ... and against the pipeline assembled from installed third-party code (torch.stft, transformers.audio_utils, scipy):
     # pins the device STFT-as-GEMM / mel / dB / DCT stages independently of this repo's own numpy twin
     from conftest import third_party_mfcc
-    np.testing.assert_allclose(got22, third_party_mfcc(x), atol=0.05, rtol=2e-4)
+    np.testing.assert_allclose(got22, third_party_mfcc(x), atol=2e-3, rtol=2e-4)
     x22 = fe.resample_sinc_hann(wav[None], 16000, 22000)[0]                  # resampler itself: unpinned, shared
-    np.testing.assert_allclose(dev[0], third_party_mfcc(x22), atol=0.05, rtol=2e-4)
+    np.testing.assert_allclose(dev[0], third_party_mfcc(x22), atol=2e-3, rtol=2e-4)
     p = str(tmp_path / "a.wav")
     wavfile.write(p, 16000, np.stack([wav, wav2], 1))                       # stereo float wav
     a = fe.get_mfcc_ta(p, sr=22000, fps=30)                                    # device path
     b = fe.get_mfcc_ta(p, sr=22000, fps=30, host=True)                         # numpy path
     assert a.shape == b.shape and a.shape[1] == 64
-    np.testing.assert_allclose(a, b, atol=0.05, rtol=2e-4)
+    np.testing.assert_allclose(a, b, atol=2e-3, rtol=2e-4)
 
 
 def test_wav_in_code_stability(hip, tmp_path):
