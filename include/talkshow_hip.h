@@ -53,29 +53,6 @@ const char *ts_version(void);
 /* Non-blocking HIP streams for keeping several independent batches in flight on one GPU (the library keeps one
  * scratch arena per stream; weights are shared).  *out is a hipStream_t. */
 int ts_stream_create(ts_ctx *ctx, void **out);
-/* Like ts_stream_create, but kernels of this stream only run on compute units [cu_first, cu_first+cu_count) of the
- * device's CU-mask index space (hipExtStreamCreateWithCUMask).  No reference counterpart. */
-int ts_stream_create_cus(ts_ctx *ctx, int cu_first, int cu_count, void **out_stream);
-/* Tuning aid: with TS_SKINNY_TRACE=1 the chain kernel stamps the device wall clock (100 MHz) at five points; this reads
- * (and resets) the records, 6 uint64 each.  Returns the number of records or -1. */
-int ts_debug_skinny_trace(unsigned long long *out, int max_records);
-/* Measurement aid: launches a one-wave kernel on `stream` that, every window_us for n windows, writes three uint64 to dev_out
- * (device memory, 3 n values): wall-clock ticks (100 MHz) since its start, ticks of this window, shader-clock cycles of this
- * window — the clock the chip actually sustains while other streams load it (tools/conv_clock.py).  No reference counterpart. */
-int ts_debug_clock_sample(unsigned long long *dev_out, int n, int window_us, void *stream);
-/* Tuning aid: with TS_CHAIN_TRACE=1 one workgroup of the persistent chain kernel stamps the device wall clock (100 MHz) six times per
- * stage; this copies the last launch's records, 8 uint64 per stage (tools/persist_trace.py).  Returns the number of stages or -1. */
-int ts_debug_chain_trace(unsigned long long *out, int max_stages);
-/* Host-only helper (no GPU needed): how `conv_gemm_f32` launches an (M rows x N columns, `groups` problems) layer that takes 128 x 128
- * tiles — out4 = {row blocks tiled 128 x 128, row blocks tiled 64 x 128, workgroups of the first band, workgroups in all}.  Returns 1 if the
- * layer is launched in two bands (more than one round of 512 resident workgroups, not a whole number of rounds), 0 for a plain grid,
- * -1 on a bad argument.  No reference counterpart. */
-int ts_debug_conv_bands(int M, int N, int groups, int *out4);
-/* Host-only helper (no GPU needed): the TILED copy of a row-major weight matrix W[N][ldw] (K columns used) that the
- * PixelCNN chain kernel multiplies with — every 16-column x 16-k operand fragment one contiguous KB in lane order
- * (DESIGN.md §3/§4); epi 0 = linear column order, 1 = gate (8 tanh channels + their 8 sigmoid partners per tile,
- * gateD channels per half).  out holds ceil(N/16) * (K/16) * 256 floats.  K % 16 == 0.  No reference counterpart. */
-int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int gateD, float *out);
 int ts_stream_destroy(ts_ctx *ctx, void *stream);
 
 /* ---- AudioEncoder(in_dim=64, num_hiddens, num_residual_layers, ·)  — vqvae_1d.py:11-34 ------------------ */
@@ -135,7 +112,12 @@ void ts_pixelcnn_destroy(ts_pixelcnn *pix);
  *   (clip b draws from subsequence clip_index0 + b, so results do not depend on how clips are sharded);
  *   logits_dev optional (B,H,2,input_dim) fp32: logits of every position as the reference's forward gives them.
  *   pre_codes_dev / pre_aud_dev / H0: optional continuity prefix (gated_pixelcnn_v2.py:158-165): H0 rows of
- *   already generated codes (B,H0,2) and their audio features (B,H0,aud_dim); pass NULL, NULL, 0 otherwise. */
+ *   already generated codes (B,H0,2) and their audio features (B,H0,aud_dim); pass NULL, NULL, 0 otherwise.
+ *   Philox position rule (since round 3): the counter word of a code is its ABSOLUTE grid position (row * 2 + column) with
+ *   the prefix rows counted — the first generated row of a call with H0 prefix rows draws at positions 2 H0, 2 H0 + 1 — so a
+ *   clip generated as head + prefix-continued tail (or in ts_pixelcnn_stream_step chunks) draws exactly what one call over
+ *   all its rows draws.  (Rounds 1-2 restarted at position 0 behind a prefix: sampled codes of H0 > 0 calls differ from those
+ *   builds for the same seed.)  uniforms_dev always holds the H GENERATED rows only, (B,H,2). */
 int ts_pixelcnn_generate(ts_pixelcnn *pix, const int64_t *label_dev, const float *aud_dev, int B, int H, int mode,
                          const float *uniforms_dev, uint64_t seed, int64_t clip_index0, int64_t *codes_dev,
                          float *logits_dev, const int64_t *pre_codes_dev, const float *pre_aud_dev, int H0,
@@ -220,18 +202,6 @@ int ts_op_sample_philox(ts_ctx *ctx, const float *logits_dev, int B, int V, uint
  * lower-body values part2full inserts (`lower_pose`, or zeros with [6:9] = global orientation when stand=True). */
 int ts_assemble_full(ts_ctx *ctx, const float *body_dev, int Tb, const float *face_dev, int Tf, int B,
                      const float *lower_pose33_host, float *out_dev, void *stream);
-
-/* Tuning / roofline entry (not part of the drop-in surface): a stride-1 conv layer (K = 1 or 3, Cin % 32 == 0)
- * whose weights are ALREADY packed on the device as [round128(Cout)][K*Cin] (tap-major, k contiguous), launched
- * `iters` times between two HIP events recorded on `stream`; tile: 0 = production heuristic, 1 = 128x128,
- * 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 with 64-deep K chunks, 6 = 160x128, 7 = 96x128.  *ms_out = mean launch duration in milliseconds. */
-int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
-                       const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
-                       void *stream);
-
-/* Tuning entry (not part of the drop-in surface): `iters` DEPENDENT skinny_gemm launches replayed from one hipGraph;
- * *us_out = microseconds per launch.  gate != 0: N = 2K with the tanh*sigmoid epilogue; debug: unused. */
-int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int debug, float *us_out);
 
 /* ---- instrumentation ---------------------------------------------------------------------------------------- */
 /* Per-kernel-family device time of the calls made on this context since the last reset, measured with HIP

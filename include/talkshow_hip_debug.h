@@ -1,0 +1,54 @@
+/*
+ * talkshow_hip_debug.h — measurement, tuning and test aids of libtalkshow_hip.so.
+ *
+ * NOT part of the drop-in surface (include/talkshow_hip.h): nothing here has a counterpart in the reference, no product code under
+ * nets/ or evaluation/ calls these, and they may change between rounds.  Clients: tools/ (profiling / A-B scripts) and tests/
+ * (host-side layout and launch-plan checks, tile-shape agreement, the shader-clock sampler).  Same conventions as the main header
+ * (0 on success unless stated, ts_last_error() for the message).
+ */
+#ifndef TALKSHOW_HIP_DEBUG_H
+#define TALKSHOW_HIP_DEBUG_H
+
+#include "talkshow_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Like ts_stream_create, but kernels of this stream only run on compute units [cu_first, cu_first+cu_count) of the
+ * device's CU-mask index space (hipExtStreamCreateWithCUMask).  No reference counterpart. */
+int ts_stream_create_cus(ts_ctx *ctx, int cu_first, int cu_count, void **out_stream);
+/* Tuning aid: with TS_SKINNY_TRACE=1 the chain kernel stamps the device wall clock (100 MHz) at five points; this reads
+ * (and resets) the records, 6 uint64 each.  Returns the number of records or -1. */
+int ts_debug_skinny_trace(unsigned long long *out, int max_records);
+/* Measurement aid: launches a one-wave kernel on `stream` that, every window_us for n windows, writes three uint64 to dev_out
+ * (device memory, 3 n values): wall-clock ticks (100 MHz) since its start, ticks of this window, shader-clock cycles of this
+ * window — the clock the chip actually sustains while other streams load it (tools/conv_clock.py).  No reference counterpart. */
+int ts_debug_clock_sample(unsigned long long *dev_out, int n, int window_us, void *stream);
+/* Host-only helper (no GPU needed): how `conv_gemm_f32` launches an (M rows x N columns, `groups` problems) layer that takes 128 x 128
+ * tiles — out4 = {row blocks tiled 128 x 128, row blocks tiled 64 x 128, workgroups of the first band, workgroups in all}.  Returns 1 if the
+ * layer is launched in two bands (more than one round of 512 resident workgroups, not a whole number of rounds), 0 for a plain grid,
+ * -1 on a bad argument.  No reference counterpart. */
+int ts_debug_conv_bands(int M, int N, int groups, int *out4);
+/* Host-only helper (no GPU needed): the TILED copy of a row-major weight matrix W[N][ldw] (K columns used) that the
+ * PixelCNN chain kernel multiplies with — every 16-column x 16-k operand fragment one contiguous KB in lane order
+ * (DESIGN.md §3/§4); epi 0 = linear column order, 1 = gate (8 tanh channels + their 8 sigmoid partners per tile,
+ * gateD channels per half).  out holds ceil(N/16) * (K/16) * 256 floats.  K % 16 == 0.  No reference counterpart. */
+int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int gateD, float *out);
+
+/* Tuning / roofline entry (not part of the drop-in surface): a stride-1 conv layer (K = 1 or 3, Cin % 32 == 0)
+ * whose weights are ALREADY packed on the device as [round128(Cout)][K*Cin] (tap-major, k contiguous), launched
+ * `iters` times between two HIP events recorded on `stream`; tile: 0 = production heuristic, 1 = 128x128,
+ * 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 with 64-deep K chunks, 6 = 160x128, 7 = 96x128.  *ms_out = mean launch duration in milliseconds. */
+int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
+                       const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
+                       void *stream);
+
+/* Tuning entry (not part of the drop-in surface): `iters` DEPENDENT skinny_gemm launches replayed from one hipGraph;
+ * *us_out = microseconds per launch.  gate != 0: N = 2K with the tanh*sigmoid epilogue; debug: unused. */
+int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int debug, float *us_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TALKSHOW_HIP_DEBUG_H */

@@ -85,7 +85,7 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.g_hand.decode_nlc(latents[..., 1].contiguous(), out=out, col0=self.each_dim[1])
         return out
 
-    def generate_batch(self, mfcc, ids, mode=_lib.TS_SAMPLE_PHILOX, uniforms=None, seed=None, clip_index0=0):
+    def generate_batch(self, mfcc, ids, mode=_lib.TS_SAMPLE_PHILOX, uniforms=None, seed=None, clip_index0=0, _ids_checked=False):
         """Batched device entry (one call into the C ABI): mfcc (B,T,64), ids (B,) -> codes (B,H,2), poses (B,4H,129).
 
         This is what `infer_on_audio` runs after the front-end, for B different clips; bench.py and the multi-GPU
@@ -93,7 +93,10 @@ class TrainWrapper(TrainWrapperBaseClass):
         """
         dev = self.generator._dev()
         mfcc = torch.as_tensor(mfcc, dtype=torch.float32, device=dev).contiguous()
-        ids = _index_tensor(ids, self.num_classes, 'speaker id', dev)   # IndexError like nn.Embedding; host inputs are checked without a sync
+        if _ids_checked:   # generate_batches range-checked every batch's ids before stacking them (no sync on the stacked tensor)
+            ids = torch.as_tensor(ids, dtype=torch.int64, device=dev).reshape(-1).contiguous()
+        else:
+            ids = _index_tensor(ids, self.num_classes, 'speaker id', dev)   # IndexError like nn.Embedding; host inputs are checked without a sync
         B, T, _ = mfcc.shape
         H = T // 2 // 2
         # nn.Embedding of a single label broadcasts over the batch in the reference (gated_pixelcnn_v2.py:65-66)
@@ -102,7 +105,7 @@ class TrainWrapper(TrainWrapperBaseClass):
         if ids.numel() != B:
             raise ValueError(f"ids must hold 1 or B={B} speaker indices, got {ids.numel()}")
         if seed is None:   # like the reference, which draws from torch's generator on every call: repeated calls differ
-            seed = _fresh_seed()
+            seed = _fresh_seed() if mode == _lib.TS_SAMPLE_PHILOX else 0     # greedy / injected uniforms never read it
         codes = torch.zeros((B, H, 2), dtype=torch.int64, device=dev)
         poses = torch.empty((B, 4 * H, self.each_dim[1] + self.each_dim[2]), dtype=torch.float32, device=dev)
         if uniforms is not None:
@@ -123,11 +126,17 @@ class TrainWrapper(TrainWrapperBaseClass):
         mfccs: list of (B_i,T,64) device tensors, ids_list: list of (B_i,) -> list of (codes_i, poses_i) views."""
         dev = self.generator._dev()
         sizes = [int(m.shape[0]) for m in mfccs]
+        # nn.Embedding's IndexError per submitted batch, BEFORE stacking: host ids are checked on the host, a caller-owned device
+        # tensor once per tensor version (modules._check_index_range) — the stacked tensor built below is new on every call, and
+        # checking it would cost the serving path one blocking device -> host read per pass (ADVICE r3)
+        from talkshow_amd.modules import _check_index_range
+        for i in ids_list:
+            _check_index_range(i, self.num_classes, 'speaker id')
         mf = torch.cat([torch.as_tensor(m, dtype=torch.float32, device=dev) for m in mfccs], 0)
         ids = torch.cat([torch.as_tensor(i, dtype=torch.int64, device=dev).reshape(-1).expand(b) if
                          torch.as_tensor(i).numel() == 1 else torch.as_tensor(i, dtype=torch.int64, device=dev).reshape(-1)
                          for i, b in zip(ids_list, sizes)], 0)
-        codes, poses = self.generate_batch(mf, ids, mode=mode, seed=seed, clip_index0=clip_index0)
+        codes, poses = self.generate_batch(mf, ids, mode=mode, seed=seed, clip_index0=clip_index0, _ids_checked=True)
         return list(zip(codes.split(sizes, 0), poses.split(sizes, 0)))
 
     def infer_on_audio(self, aud_fn, initial_pose=None, norm_stats=None, exp=None, var=None, w_pre=False, rand=None,
@@ -165,7 +174,7 @@ class TrainWrapper(TrainWrapperBaseClass):
             mode = _lib.TS_SAMPLE_UNIFORMS
         seed = kwargs.get('seed', None)
         if seed is None:
-            seed = _fresh_seed()
+            seed = _fresh_seed() if mode == _lib.TS_SAMPLE_PHILOX else 0
 
         with torch.no_grad():
             aud_feat = aud_feat.permute(0, 2, 1)                      # (B, T, 64)
@@ -177,8 +186,10 @@ class TrainWrapper(TrainWrapperBaseClass):
                 u0 = u1 = None
                 if uniforms is not None:                                 # (B, H, 2) for the whole clip: split at the seam's code row
                     uniforms = torch.as_tensor(uniforms, dtype=torch.float32)
-                    h0 = gap // 4
-                    u0, u1 = uniforms[:, :h0].contiguous(), uniforms[:, h0:].contiguous()
+                    h0, h1 = gap // 4, (aud_feat.shape[1] - gap) // 4    # code rows of the two parts (each loses its own remainder)
+                    if tuple(uniforms.shape) != (B, h0 + h1, 2):
+                        raise ValueError(f"continuity: uniforms must have shape (B={B}, {h0} + {h1} code rows, 2), got {tuple(uniforms.shape)}")
+                    u0, u1 = uniforms[:, :h0].contiguous(), uniforms[:, h0:h0 + h1].contiguous()
                 part0 = session.push(aud_feat[:, :gap], mode=mode, seed=seed, uniforms=u0)
                 part1 = session.push(aud_feat[:, gap:], mode=mode, seed=seed, uniforms=u1)
                 session.close()

@@ -2,29 +2,33 @@
 """TEST INFRASTRUCTURE (checker side only; nothing under talkshow_amd/, nets/ or evaluation/ may import this).
 
 Compiles the reference's own CALLER code — the functions of `scripts/demo.py` and `scripts/test_body.py` that drive the
-`nets` package, plus the two helper modules they import from the reference tree — into `oracle/_ref/reference_callers.bin`
-(code objects, the Python analogue of a compiled `oracle/_ref/*.so`; the directory is git-ignored and travels to the GPU box
-with the snapshot).  `tests/test_reference_callers.py` executes those code objects against THIS repository's `nets`,
+`nets` package, plus the two helper modules they import from the reference tree — into `oracle/_ref/<unit>.code` + `oracle/_ref/reference_callers.json`
+(code objects, the Python analogue of a compiled `oracle/_ref/*.so`, and a manifest of sha256 hashes; the directory is
+git-ignored and travels to the GPU box with the snapshot).  `tests/test_reference_callers.py` executes those code objects against THIS repository's `nets`,
 `evaluation` and SMPL-X layer on the GPU: the reference's callers driven against the drop-in, not an imitation of their call
-shapes.  No reference source text is written anywhere.
+shapes.  No reference source text is written anywhere (which is why the units are code objects and not `.py` files: the manifest
+names file, lifted names and hashes so that what runs can be checked against the reference tree it came from).  The files are
+raw `marshal` of ONE code object each — no pickle — and `load()` verifies every hash before unmarshalling anything.
 
 What is lifted (by AST, so that the scripts' argument parsing, dataset and renderer imports stay out):
     scripts/demo.py        init_model (:30-64), infer (:158-247), the module-level `device` / `global_orient` assignments
     scripts/test_body.py   init_model (:30-56), body_loss (:98-110), test (:113-194)
     data_utils/lower_body.py, data_utils/get_j.py   whole modules (they import numpy / torch only)
 
-    python oracle/build_ref_callers.py            # needs /root/reference; run by __graft_entry__.build() when it exists
+    python oracle/build_ref_callers.py            # needs /root/reference; __graft_entry__.build() runs it where that exists
+                                                  # (TS_SKIP_REF_CALLERS=1 opts out; a failure there is a warning + skipped tests)
 """
 import ast
 import hashlib
+import json
 import marshal
 import os
-import pickle
 import sys
 
 REF = os.environ.get("TALKSHOW_REFERENCE", "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "_ref", "reference_callers.bin")
+OUT_DIR = os.path.join(HERE, "_ref")
+MANIFEST = os.path.join(OUT_DIR, "reference_callers.json")
 
 UNITS = {   # unit -> (file, names to keep: None = the whole module; functions and top-level assignments by name)
     "demo": ("scripts/demo.py", ["init_model", "infer", "device", "global_orient"]),
@@ -34,8 +38,19 @@ UNITS = {   # unit -> (file, names to keep: None = the whole module; functions a
 }
 
 
+class RefCallersError(RuntimeError):
+    """The lift could not be made (reference tree absent or laid out differently) or a built file fails its integrity check."""
+
+
+def _sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
 def lift(path, names):
-    src = open(path, encoding="utf-8").read()
+    try:
+        src = open(path, encoding="utf-8").read()
+    except OSError as e:
+        raise RefCallersError(f"cannot read {path}: {e}")
     tree = ast.parse(src, filename=path)
     if names is not None:
         keep = []
@@ -48,35 +63,63 @@ def lift(path, names):
                                                                  if isinstance(t, ast.Name)}
         missing = [n for n in names if n not in found]
         if missing:
-            raise SystemExit(f"{path}: not found: {missing}")
+            raise RefCallersError(f"{path}: not found: {missing} (the reference's layout changed?)")
         tree = ast.Module(body=keep, type_ignores=[])
     rel = os.path.relpath(path, REF)
-    return compile(tree, f"<reference {rel}>", "exec"), hashlib.sha256(src.encode()).hexdigest()
+    return compile(tree, f"<reference {rel}>", "exec"), _sha(src.encode())
 
 
-def build(out=OUT):
+def build(out_dir=OUT_DIR):
+    """Writes one `<unit>.code` file (a marshalled code object — nothing else, no pickle) per unit and a JSON manifest that names,
+    for every unit, the reference file it came from, that file's sha256, the names lifted and the sha256 of the `.code` bytes.
+    Raises RefCallersError where the reference tree is absent or laid out differently."""
     if not os.path.isdir(REF):
-        raise SystemExit(f"{REF} does not exist: the reference callers can only be built where the reference tree is")
-    units, files = {}, {}
+        raise RefCallersError(f"{REF} does not exist: the reference callers can only be built where the reference tree is")
+    os.makedirs(out_dir, exist_ok=True)
+    manifest = {"python": list(sys.version_info[:2]), "units": {}}
     for unit, (rel, names) in UNITS.items():
-        code, sha = lift(os.path.join(REF, rel), names)
-        units[unit] = marshal.dumps(code)
-        files[rel] = sha
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    with open(out, "wb") as f:
-        pickle.dump({"python": list(sys.version_info[:2]), "files": files, "units": units,
-                     "what": {u: {"file": r, "names": n} for u, (r, n) in UNITS.items()}}, f)
-    return out
+        code, src_sha = lift(os.path.join(REF, rel), names)
+        blob = marshal.dumps(code)
+        with open(os.path.join(out_dir, unit + ".code"), "wb") as f:
+            f.write(blob)
+        manifest["units"][unit] = {"file": rel, "names": names, "source_sha256": src_sha, "code_sha256": _sha(blob),
+                                   "code_bytes": len(blob)}
+    with open(os.path.join(out_dir, "reference_callers.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    stale = os.path.join(out_dir, "reference_callers.bin")          # the pickle of earlier rounds
+    if os.path.exists(stale):
+        os.remove(stale)
+    return os.path.join(out_dir, "reference_callers.json")
 
 
-def load(path=OUT):
-    """-> {unit: code object} (None if the file is absent or was built by another Python version)."""
+def load(out_dir=OUT_DIR):
+    """-> ({unit: code object}, manifest), or None if nothing was built here / it was built by another Python version.
+
+    Every `.code` file must hash to what the manifest says (and, where the reference tree is present, every reference file
+    to the hash it had when lifted) before a single byte of it is unmarshalled: a file that fails raises RefCallersError, it is
+    never executed.  The unit set and file names are fixed by UNITS above, not by the manifest."""
+    path = os.path.join(out_dir, "reference_callers.json")
     if not os.path.exists(path):
         return None
-    d = pickle.load(open(path, "rb"))
-    if list(sys.version_info[:2]) != d["python"]:
+    m = json.load(open(path))
+    if list(sys.version_info[:2]) != m.get("python"):
         return None
-    return {u: marshal.loads(b) for u, b in d["units"].items()}, d
+    units = {}
+    for unit, (rel, names) in UNITS.items():
+        ent = m.get("units", {}).get(unit)
+        if not ent or ent.get("file") != rel or ent.get("names") != names:
+            raise RefCallersError(f"{path}: entry for unit {unit!r} does not match build_ref_callers.UNITS")
+        try:
+            blob = open(os.path.join(out_dir, unit + ".code"), "rb").read()
+        except OSError as e:
+            raise RefCallersError(f"{unit}.code named by the manifest is unreadable: {e}")
+        if len(blob) != ent.get("code_bytes") or _sha(blob) != ent.get("code_sha256"):
+            raise RefCallersError(f"{unit}.code does not hash to the manifest's code_sha256: refusing to load it")
+        ref_file = os.path.join(REF, rel)
+        if os.path.exists(ref_file) and _sha(open(ref_file, "rb").read()) != ent.get("source_sha256"):
+            raise RefCallersError(f"{rel} changed since the callers were lifted: rebuild (python oracle/build_ref_callers.py)")
+        units[unit] = marshal.loads(blob)
+    return units, m
 
 
 if __name__ == "__main__":

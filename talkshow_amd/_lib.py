@@ -1,4 +1,4 @@
-"""ctypes binding of libtalkshow_hip.so (C ABI: include/talkshow_hip.h).
+"""ctypes binding of libtalkshow_hip.so (C ABI: include/talkshow_hip.h; tuning / test aids: include/talkshow_hip_debug.h).
 
 There is NO fallback: if the library has not been built, or no gfx950 device is present when a context is
 requested, this module raises.  PyTorch is imported first on purpose — the library must share the HIP runtime
@@ -22,7 +22,7 @@ class TsTensor(C.Structure):
 
 _vp, _i, _i64, _u64, _fp = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.POINTER(C.c_float)
 
-# name -> (restype, argtypes); every symbol include/talkshow_hip.h declares
+# name -> (restype, argtypes); every symbol include/*.h declares
 SIGNATURES = {
     "ts_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "ts_ctx_destroy": (None, [_vp]),
@@ -32,7 +32,6 @@ SIGNATURES = {
     "ts_stream_create_cus": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
     "ts_debug_skinny_trace": (_i, [C.POINTER(C.c_uint64), _i]),
     "ts_debug_clock_sample": (_i, [_vp, _i, _i, _vp]),
-    "ts_debug_chain_trace": (_i, [C.POINTER(C.c_uint64), _i]),
     "ts_debug_conv_bands": (_i, [_i, _i, _i, C.POINTER(_i)]),
     "ts_debug_tile_weights": (_i, [_vp, _i, _i, C.c_long, _i, _i, _vp]),
     "ts_assemble_full": (_i, [_vp, _vp, _i, _vp, _i, _i, _fp, _vp, _vp]),

@@ -18,6 +18,28 @@ BodyWork &body_work(hipStream_t s) {
 }
 }  // namespace
 
+namespace ts {
+const Knobs &knobs() {
+    static const Knobs k = [] {
+        Knobs v;
+        auto num = [](const char *name, int dflt) { const char *e = std::getenv(name); return e && e[0] ? std::atoi(e) : dflt; };
+        v.conv_bands = num("TS_CONV_BANDS", 1) != 0;
+        v.prof_log = num("TS_PROF_LOG", 0) != 0;
+        if (const char *e = std::getenv("TS_NO_GRAPH")) v.no_graph = e[0] && e[0] != '0';
+        v.pix_defer_p = num("TS_PIX_DEFER_P", -1);
+        v.skinny_v = num("TS_SKINNY_V", 1);
+        v.skinny_nt = num("TS_SKINNY_NT", 16);
+        v.skinny_tiled = num("TS_SKINNY_TILED", 1) != 0;
+        v.wide_min = num("TS_SKINNY_WIDE_MIN", 160);
+        v.skinny_shape = num("TS_SKINNY_SHAPE", 0);
+        v.skinny_trace = num("TS_SKINNY_TRACE", 0);
+        v.wide_ablate = num("TS_SKINNY_WIDE_ABLATE", 0);
+        return v;
+    }();
+    return k;
+}
+}  // namespace ts
+
 extern "C" {
 
 // Streams for pipelining independent batches.  Created back to back so that ROCclr's round-robin hands consecutive
@@ -68,8 +90,6 @@ int ts_debug_clock_sample(unsigned long long *dev_out, int n, int window_us, voi
     TS_HIP(ts::launch_clock_sample(dev_out, n, (unsigned long long)window_us * 100, (hipStream_t)stream));
     return 0;
 }
-// tuning aid (TS_CHAIN_TRACE=1): per-stage wall-clock stamps of the persistent chain kernel's last launch, 8 uint64 per stage
-int ts_debug_chain_trace(unsigned long long *out, int max_stages) { return ts::chain_trace_read(out, max_stages); }
 // Host-only (no GPU): the launch plan of an (M x N, `groups` problems) conv layer — out4 = {row blocks of 128 x 128 tiles, row blocks of
 // 64 x 128 tiles, workgroups of the first band, workgroups}; returns 1 if the layer is launched in two bands, 0 for a plain grid
 int ts_debug_conv_bands(int M, int N, int groups, int *out4) {

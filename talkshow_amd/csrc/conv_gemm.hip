@@ -398,7 +398,7 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
     // zero buffer (ts::skinny_init, called by ts_ctx_create): 64 Ki floats; parked pointers walk at most Ktot floats of it
     if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000) return hipErrorInvalidValue;
     if (tile == 0 && pick_tile(p) == 1) {
-        static const bool banded = !(getenv("TS_CONV_BANDS") && atoi(getenv("TS_CONV_BANDS")) == 0);   // 0: plain grid (A/B, tests)
+        const bool banded = knobs().conv_bands;   // TS_CONV_BANDS=0: plain grid (A/B, tests)
         ConvBands bd;
         if (banded && plan_bands(p, bd)) {
             hipLaunchKernelGGL((conv_gemm_banded_kernel<64, 128, 32, 64>), dim3(bd.total), block, 0, stream, p, bd);

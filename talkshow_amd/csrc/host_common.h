@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/talkshow_hip.h"
+#include "../../include/talkshow_hip_debug.h"
 #include "kernels.h"
 
 namespace ts {

@@ -164,6 +164,26 @@ hipError_t launch_i64_to_i32(const int64_t *src, int *dst, long n, hipStream_t s
 // measurement aid: n records of (wall ticks since start, wall ticks of the window, shader cycles of the window), 100 MHz wall clock
 hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long long window_ticks, hipStream_t stream);
 
+// ------------------------------------------------------------------------------------------------
+// Test / A-B levers (INTEGRATION.md has the table).  Every TS_* environment variable the library knows is read ONCE, by the
+// first ts_ctx_create of the process (api.cpp), into this struct; nothing on a launch path calls getenv.  All paths behind
+// them are bit-identical on a clip's codes (tests/test_gpu_parity.py::test_alternate_kernel_paths).
+// ------------------------------------------------------------------------------------------------
+struct Knobs {
+    bool conv_bands = true;     // TS_CONV_BANDS=0: big conv layers as one plain grid of 128 x 128 tiles
+    bool prof_log = false;      // TS_PROF_LOG=1: one stderr line per conv launch while ts_prof is enabled
+    bool no_graph = false;      // TS_NO_GRAPH=1: PixelCNN launches go out eagerly
+    int pix_defer_p = -1;       // TS_PIX_DEFER_P: -1 auto (<= 128 clips), 0 / 1 forced
+    int skinny_v = 1;           // TS_SKINNY_V=0: generic chain kernels
+    int skinny_nt = 16;         // TS_SKINNY_NT=32: 32-column generic kernel
+    bool skinny_tiled = true;   // TS_SKINNY_TILED=0: row-major chain operands
+    int wide_min = 160;         // TS_SKINNY_WIDE_MIN: workgroups from which a coalesced launch takes the wide kernel (0 never, 1 always)
+    int skinny_shape = 0;       // TS_SKINNY_SHAPE=11|21|22|42: forced split-K tile shape
+    int skinny_trace = 0;       // TS_SKINNY_TRACE=1: in-kernel clock stamps (tools/skinny_trace.py, tools/wide_trace.py)
+    int wide_ablate = 0;        // TS_SKINNY_WIDE_ABLATE=2|4 (trace builds): no loads / no MFMAs in the wide kernel
+};
+const Knobs &knobs();
+
 // exp(x) for x <= 0 from fp32 multiplies and adds ONLY (no fused multiply-add, no hardware transcendental): every operation is
 // one IEEE round-to-nearest fp32 operation, so `oracle/talkshow_oracle.py::det_expf` reproduces it bit for bit on any host and
 // the inverse-CDF draw of a given uniform is the same index on the device and in the oracle — not "within one slot".

@@ -94,8 +94,7 @@ int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s) {
     if (ctx->prof.on) {
         ctx->prof.begin(FAM_CONV, s);
         ctx->prof.flops[FAM_CONV] += conv_gemm_flops(p);
-        static const bool log = getenv("TS_PROF_LOG") && atoi(getenv("TS_PROF_LOG"));
-        if (log) {
+        if (ts::knobs().prof_log) {
             char buf[128];
             snprintf(buf, sizeof(buf), "conv M=%d N=%d K=%d groups=%d z=%d stride=%d Lout=%d", p.M, p.N, p.Ktot, p.ngroups, p.zdiv,
                      p.stride, p.Lout);
@@ -634,6 +633,7 @@ int ts_ctx_create(int device, ts_ctx **out) {
     TS_HIP(hipGetDeviceProperties(&prop, device));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
         return fail(std::string("ts_ctx_create: this library is built for gfx950 (MI355X) only, device is ") + prop.gcnArchName);
+    (void)ts::knobs();   // every TS_* test lever is parsed here, once per process; launch paths only read the struct
     std::unique_ptr<ts_ctx> c(new ts_ctx());
     c->device = device;
     const int m1 = -1;

@@ -87,15 +87,9 @@ struct ts_pixelcnn {
         hipStream_t cap_stream = nullptr;
         std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
         std::map<std::tuple<int, int, int, int>, std::pair<long, double>> graph_stats;   // skinny launches, flops
-        // passes of 128 / 256 / 384 / 512 clips: the stages of the whole chain, recorded once and run by ONE persistent kernel
-        // (skinny_persist.hip); n = 0: this shape does not fit it and keeps the hipGraph of launches
-        struct PersistPlan { DevBuf stages; int n = 0; };
-        std::map<std::tuple<int, int, int, int>, std::unique_ptr<PersistPlan>> plans;
-        DevBuf chain_sync;
         void drop_graphs() {
             for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
             graphs.clear();
-            plans.clear();   // recorded stages hold the same buffer pointers
         }
         ~Work() {
             drop_graphs();
@@ -805,8 +799,8 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
         TS_TRY(tile(p->w1m, p->HID, NL >= 2 ? D2 : D, NL >= 2 ? D2 : D, EPI_LINEAR, 0));
         TS_TRY(tile(p->w2, V, p->HID, p->HID, EPI_LINEAR, 0));
     }
-    if (const char *e = std::getenv("TS_NO_GRAPH")) p->use_graph = !(e[0] && e[0] != '0');
-    if (const char *e = std::getenv("TS_PIX_DEFER_P")) p->defer_p = std::atoi(e);
+    if (ts::knobs().no_graph) p->use_graph = false;
+    if (ts::knobs().pix_defer_p >= 0) p->defer_p = ts::knobs().pix_defer_p;
     *out = p.release();
     return 0;
 }
@@ -889,40 +883,6 @@ int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const
     dh[1] = (uint64_t)c.clip0;
     dh[2] = (uint64_t)c.pos_base;
     TS_HIP(hipMemcpyAsync(w->dyn.p, dh, 3 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    // ---- persistent chain kernel (skinny_persist.hip) for whole-XCD pass sizes ----
-    // Opt-in (TS_CHAIN_PERSIST=1; 2 = two workgroups per CU): bit-identical to the launch graph, and still slower than it — 44 vs 32 ms
-    // per 256-clip pass; DESIGN.md §4 has the per-stage timeline and what the tile engine lacks.
-    static const int persist = [] { const char *e = getenv("TS_CHAIN_PERSIST"); return e ? atoi(e) : 0; }();
-    if (persist > 0 && (c.B == 128 || c.B == 256)) {   // 16 / 32 clips per XCD (more would spill the pipelined kernel's registers)
-        auto pit = w->plans.find(key);
-        if (pit == w->plans.end()) {
-            ChainRecorder rec;
-            rec.M = c.B;
-            const long l0 = ctx->n_launch[FAM_SKINNY];
-            const double f0 = ctx->n_flops[FAM_SKINNY];
-            chain_record_set(&rec);
-            const int rc = row_loop(nullptr);
-            chain_record_set(nullptr);
-            if (rc != 0) return rc;
-            std::unique_ptr<ts_pixelcnn::Work::PersistPlan> pl(new ts_pixelcnn::Work::PersistPlan());
-            if (rec.ok && !rec.stages.empty()) {
-                TS_TRY(pl->stages.upload(rec.stages.data(), rec.stages.size() * sizeof(ChainStage)));
-                TS_TRY(w->chain_sync.ensure(sizeof(ChainSync)));
-                pl->n = (int)rec.stages.size();
-                w->graph_stats[key] = {ctx->n_launch[FAM_SKINNY] - l0, ctx->n_flops[FAM_SKINNY] - f0};
-            } else if (getenv("TS_CHAIN_PERSIST_DEBUG")) {
-                fprintf(stderr, "[ts] persistent chain: pass of %d clips keeps the launch graph (%zu stages recorded, ok=%d)\n", c.B,
-                        rec.stages.size(), (int)rec.ok);
-            }
-            pit = w->plans.emplace(key, std::move(pl)).first;
-        }
-        if (pit->second->n > 0) {
-            TS_HIP(launch_chain_persist(static_cast<const ChainStage *>(pit->second->stages.p), pit->second->n,
-                                        static_cast<ChainSync *>(w->chain_sync.p), c.B, persist, s));
-            TS_HIP(hipMemcpyAsync(codes, w->codes_int.p, (size_t)c.B * c.H * 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-            return 0;
-        }
-    }
     auto it = w->graphs.find(key);
     if (it == w->graphs.end()) {
         if (!w->cap_stream) TS_HIP(hipStreamCreateWithFlags(&w->cap_stream, hipStreamNonBlocking));

@@ -44,34 +44,6 @@ struct SkinnyDescBatch {
     SkinnyDesc d[SKINNY_MAX_PROBLEMS];
 };
 
-// ---- persistent chain kernel (skinny_persist.hip): the stages of a whole pass, recorded instead of launched ----
-struct ChainStage {
-    int kind;       // 0: a skinny batch (what launch_skinny_batch would have launched), 1: the sampler (launch_sample)
-    int W;          // kind 0: waves K is split over (4 or 8) — the split the per-launch path uses for this batch
-    int ntiles;     // kind 0: 32-column tiles of all problems (per row tile)
-    int pad;
-    int start[8];   // kind 0: first tile of problem i; INT_MAX beyond the last problem
-    SkinnyDesc d[SKINNY_MAX_PROBLEMS];
-    SampleParams sp;
-};
-static_assert(offsetof(ChainStage, d) == 48 && offsetof(ChainStage, start) == 16,
-              "chain_persist_kernel reads the 12 header words (kind, W, ntiles, pad, start[8]) with one vector load in front of the descriptors");
-struct ChainSync {   // zeroed before every launch; one 128-byte line per counter
-    unsigned slot[8][32];     // [xcd][0]: workgroups of the kernel that have started on this XCD
-    unsigned arrive[8][32];   // [xcd][0]: arrivals at the stage barriers (monotonic)
-    unsigned abort_flag, pad[31];
-};
-struct ChainRecorder {
-    std::vector<ChainStage> stages;
-    int M = 0;        // clips of the pass: every recorded problem must have exactly these rows
-    bool ok = true;   // false: some launch does not fit the persistent kernel (the caller keeps the per-launch path)
-};
-// while a recorder is set (thread-local), launch_skinny_batch and launch_sample append to it and launch nothing
-ChainRecorder *chain_recorder();
-void chain_record_set(ChainRecorder *r);
-hipError_t launch_chain_persist(const ChainStage *stages, int nstages, ChainSync *sync, int clips, int wgs_per_cu, hipStream_t stream);
-int chain_trace_read(unsigned long long *out, int max_stages);
-
 // descriptor pointers are rebuilt from integers: tag them as global (address space 1) so the loads are global_load, not flat
 typedef __attribute__((address_space(1))) const float gcf;
 typedef __attribute__((address_space(1))) float gf;

@@ -628,7 +628,7 @@ hipError_t skinny_init(int device) {   // called from ts_ctx_create (never durin
     e = hipMemset(z, 0, SKINNY_ZERO_FLOATS * sizeof(float));
     if (e != hipSuccess) return e;
     g_zero[device] = z;
-    if (getenv("TS_SKINNY_TRACE") && atoi(getenv("TS_SKINNY_TRACE"))) {
+    if (knobs().skinny_trace) {
         unsigned long long *t = nullptr;
         e = hipMalloc(&t, TRACE_SLOTS * TRACE_REC * sizeof(unsigned long long));
         if (e != hipSuccess) return e;
@@ -760,7 +760,7 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
     SkinnyBatch b;
     int gx = 0, gy = 0, Q = 0;
     // column-tile width: 16 (more, leaner workgroups per stage) unless a shape needs the 8-granular 32-column kernel
-    static const int ncol_pref = [] { const char *e = getenv("TS_SKINNY_NT"); return e ? atoi(e) : 16; }();
+    const int ncol_pref = knobs().skinny_nt;
     int ncol = ncol_pref == 32 ? 32 : 16;
     if (ncol == 16)
         for (int i = 0; i < n; ++i) {
@@ -774,46 +774,18 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
         gy = gy > b.p[i].grid_y ? gy : b.p[i].grid_y;
         Q = Q > b.p[i].Ktot / 8 ? Q : b.p[i].Ktot / 8;
     }
-    if (ChainRecorder *rec = chain_recorder()) {   // a pass is being recorded for the persistent chain kernel: describe, do not launch
-        int dev = 0;
-        const int W16 = Q >= 32 ? 8 : 4;
-        ChainStage stg;
-        std::memset(&stg, 0, sizeof(stg));
-        stg.kind = 0;
-        stg.W = W16;
-        bool ok = ncol == 16 && skinny_descriptor_kernel_enabled() && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_zero[dev];
-        int total = 0;
-        for (int i = 0; i < 8; ++i) stg.start[i] = 0x7fffffff;
-        for (int i = 0; i < n && ok; ++i) {
-            const int cnt = b.p[i].Ktot / (16 * W16);
-            // rows are clips, or (clip, column) pairs clip-major (M = 2 x clips): an XCD's clips are then two row tiles
-            const int mult = b.p[i].M / rec->M;
-            ok = b.p[i].M % rec->M == 0 && (mult == 1 || mult == 2) && b.p[i].grid_x % 2 == 0 && (cnt <= 4 || rec->M == 128) &&
-                 skinny_pack_desc(b.p[i], W16, g_zero[dev], stg.d[i]);
-            stg.start[i] = total;
-            total += (b.p[i].grid_x / 2) * mult;
-        }
-        stg.ntiles = total;
-        if (!ok && rec->ok && getenv("TS_CHAIN_PERSIST_DEBUG"))
-            for (int i = 0; i < n; ++i)
-                fprintf(stderr, "[ts] persistent chain: stage %zu problem %d/%d does not fit: M=%d N=%d K=%d grid_x=%d W=%d ncol=%d\n",
-                        rec->stages.size(), i, n, b.p[i].M, b.p[i].N, b.p[i].Ktot, b.p[i].grid_x, W16, ncol);
-        if (ok) rec->stages.push_back(stg);
-        else rec->ok = false;
-        return hipSuccess;
-    }
     dim3 grid(gx, gy, n);
     // K is split over the waves of the workgroup; more waves = more loads in flight (lower latency for ONE chain) but a
     // fatter workgroup
     if (ncol == 16) {   // Q counts 8-k steps: K = 8 Q; the 16-column kernel keeps 8 accumulators -> at most 8 waves
         const int W16 = Q >= 32 ? 8 : 4;
-        static const int variant = [] { const char *e = getenv("TS_SKINNY_V"); return e ? atoi(e) : 1; }();
+        const int variant = knobs().skinny_v;
         int dev = 0;
         if (variant != 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_zero[dev]) {
             SkinnyDescBatch db;
             bool fast = true;
             // ---- wide path (skinny_wide.hip): a coalesced pass whose launch fills the chip with 64 x 64 full-K tiles ----
-            static const int wide_min = [] { const char *e = getenv("TS_SKINNY_WIDE_MIN"); return e ? atoi(e) : 160; }();
+            const int wide_min = knobs().wide_min;
             {
                 int wM = 0, Qmax = 0, Qp[SKINNY_MAX_PROBLEMS];
                 bool wide = wide_min > 0;
@@ -852,7 +824,7 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
                         for (int i = n; i < SKINNY_MAX_PROBLEMS; ++i) std::memset(&db.d[i], 0, sizeof(SkinnyDesc));
                         if (wide) {
                             db.start[6] = db.start[7] = 0;
-                            static const int wide_abl = [] { const char *e = getenv("TS_SKINNY_WIDE_ABLATE"); return e ? atoi(e) : 0; }();
+                            const int wide_abl = knobs().wide_ablate;
                             db.start[0] = g_trace_host ? wide_abl : 0;   // trace builds only: 2 = no loads, 4 = no MFMAs (problem 0 always starts at workgroup 0)
                             if (g_trace_host) {
                                 const uint64_t rec = (uint64_t)(uintptr_t)(g_trace_host + (size_t)(g_trace_seq++ % TRACE_LAUNCHES) * TRACE_WGS * TRACE_REC);
@@ -868,7 +840,7 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
             // fits one workgroup per CU (less to fetch per CU), else 32 x 16.  Coalesced batches (M >= 64): the biggest of
             // 64 x 32 / 32 x 32 / 32 x 16 that still spreads the launch over about all CUs (fewer operand bytes per output).
             constexpr int half_max = 256, fat_min = 200;
-            static const int force_shape = [] { const char *e = getenv("TS_SKINNY_SHAPE"); return e ? atoi(e) : 0; }();   // 11, 21, 22, 42 (tests)
+            const int force_shape = knobs().skinny_shape;   // 11, 21, 22, 42 (tests)
             int maxM = 0, maxcnt = 0;
             bool even = true;
             for (int i = 0; i < n; ++i) {
@@ -907,7 +879,7 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
             for (int i = n; i < SKINNY_MAX_PROBLEMS; ++i) std::memset(&db.d[i], 0, sizeof(SkinnyDesc));
             if (fast) {
                 const dim3 grid(total);
-                static const int trace = [] { const char *e = getenv("TS_SKINNY_TRACE"); return e ? atoi(e) : 0; }();
+                const int trace = knobs().skinny_trace;
                 if (trace) db.start[7] = (int)(g_trace_seq++);
                 const int shape = RB * 10 + CB;
 #define TS_SK_LAUNCH(Wv, R, C)                                                                                         \
@@ -978,11 +950,8 @@ void skinny_tile_weights(const float *W, int N, int K, long ldw, int epi, int ga
 }
 
 bool skinny_descriptor_kernel_enabled() {
-    const char *v = getenv("TS_SKINNY_V"), *nt = getenv("TS_SKINNY_NT"), *t = getenv("TS_SKINNY_TILED");
-    if (v && atoi(v) == 0) return false;
-    if (nt && atoi(nt) == 32) return false;
-    if (t && atoi(t) == 0) return false;
-    return true;
+    const Knobs &k = knobs();
+    return k.skinny_v != 0 && k.skinny_nt != 32 && k.skinny_tiled;
 }
 
 hipError_t launch_skinny_gemm(const SkinnyParams &p, hipStream_t stream) {

@@ -391,15 +391,6 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
 }
 
 hipError_t launch_sample(const SampleParams &p, hipStream_t stream) {
-    if (ChainRecorder *rec = chain_recorder()) {   // a pass is being recorded for the persistent chain kernel (skinny_persist.hip)
-        ChainStage stg;
-        std::memset(&stg, 0, sizeof(stg));
-        stg.kind = 1;
-        stg.sp = p;
-        if (p.B == rec->M && p.mode != TS_TEACHER_FORCED && !p.logits_copy) rec->stages.push_back(stg);
-        else rec->ok = false;
-        return hipSuccess;
-    }
     hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

@@ -120,9 +120,11 @@ _RIGHT = [2, 5, 8, 11, 14, 17, 19, 21]
 
 
 def lvd_symmetric(gt, pr):
-    """The symmetrical=True branch of `Batch_LVD` (`metrics.py:36-65`) on tensors of any device: gt (T,22,3), pr (B,T,22,3), equal T."""
-    if gt.shape[1] != 22 or pr.shape[2] != 22:
-        raise ValueError("symmetrical LVD is defined on the 22 SMPL-X body joints")
+    """The symmetrical=True branch of `Batch_LVD` (`metrics.py:36-65`) on tensors of any device: gt (T,J,3), pr (B,T,J,3), equal T,
+    J >= 22: the reference gathers joints 0..21 (`rearrange`), whatever else the rows carry."""
+    if gt.shape[1] < 22 or pr.shape[2] < 22:
+        raise IndexError("symmetrical LVD gathers the 22 SMPL-X body joints (indices 0..21)")
+    gt, pr = gt[:, :22], pr[:, :, :22]
     gv = (gt[1:] - gt[:-1]).norm(p=2, dim=-1)                       # (T-1, 22)
     pv = (pr[:, 1:] - pr[:, :-1]).norm(p=2, dim=-1)                 # (B, T-1, 22)
     g_side = (gv[:, _LEFT].sum(-1) > gv[:, _RIGHT].sum(-1)).to(gv.dtype)[:, None]
@@ -137,12 +139,17 @@ def lvd(gt_kps, pr_kps, symmetrical=False):
     -> 0-d float32 tensor on pr's device (the reference returns a tensor: its callers accumulate it and call `.item()`).
 
     symmetrical=False: sum over joints of |velocity magnitude difference|, averaged over frames and samples — on the device
-    (`ts_eval_body_loss`).  symmetrical=True (first 22 joints, `metrics.py:36-65`): of every mirrored joint pair only one side
+    (`ts_eval_body_loss`).  symmetrical=True (only for a 4-D `pr`, as in the reference; joints 0..21, `metrics.py:36-65`): of every mirrored joint pair only one side
     counts per frame — for gt the side whose pairs moved more in that frame; for pr the reference combines the sides as
     `left * m + right * ~m.long()` with m in {0, 1}, i.e. `~` on an INTEGER mask (-1 / -2 instead of 1 / 0): reproduced as
     written, so that numbers stay comparable with the reference's."""
     gt, pr = _dev(gt_kps).squeeze(), _dev(pr_kps).squeeze()
     if pr.ndim == 3:
+        # one sample (`metrics.py:80-94`): the reference ignores `symmetrical` here and subtracts the two velocity tracks as they
+        # are — unequal lengths are its broadcasting error, not a truncation
+        if gt.shape != pr.shape:
+            raise RuntimeError(f"LVD of one sample needs gt and pr of the same shape, got {tuple(gt.shape)} and {tuple(pr.shape)}")
+        symmetrical = False
         pr = pr[None]
     B, T, J, _ = pr.shape
     Tl = min(int(gt.shape[0]), T)

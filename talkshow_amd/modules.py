@@ -370,7 +370,7 @@ class GatedPixelCNN(NativeModule):
         if mode is None:
             mode = _lib.TS_SAMPLE_PHILOX if uniforms is None else _lib.TS_SAMPLE_UNIFORMS
         if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if mode == _lib.TS_SAMPLE_PHILOX else 0
         codes, _ = self.run(label, rows, mode=mode, uniforms=uniforms, seed=seed, pre_codes=pre_latents, pre_aud=pre_rows)
         return codes
 
@@ -411,6 +411,8 @@ class PixelCNNStream:
         codes = torch.empty((B, Hc, 2), dtype=torch.int64, device=dev)
         if uniforms is not None:
             uniforms = _dev_f32(uniforms, dev)
+            if tuple(uniforms.shape) != (B, Hc, 2):       # the library strides them by the chunk's Hc * 2: a wrong shape would misalign clips b > 0
+                raise ValueError(f"step(): uniforms must have shape (B={B}, Hc={Hc}, 2), got {tuple(uniforms.shape)}")
         _lib.check(_lib.load().ts_pixelcnn_stream_step(self._h, _lib.dptr(aud_rows), Hc, mode, _lib.dptr(uniforms),
                                                        int(seed) & (2 ** 64 - 1), int(clip_index0), _lib.dptr(codes),
                                                        _lib.stream_ptr()))

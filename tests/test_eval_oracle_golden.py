@@ -60,3 +60,10 @@ def test_symmetric_lvd_formula_vs_reference_value():
     got = float(lvd_symmetric(torch.from_numpy(g["gt_joints"]), torch.from_numpy(g["pr_joints"])))
     np.testing.assert_allclose(got, float(g["lvd_sym"]), rtol=2e-6)
     assert abs(float(g["lvd_sym"]) - float(g["lvd_plain"])) > 1e-3          # the branch does something
+    # the reference gathers joints 0..21 (`rearrange`): rows that carry more joints give the same value, fewer an IndexError
+    gt55 = np.concatenate([g["gt_joints"], np.ones((g["gt_joints"].shape[0], 33, 3), np.float32)], 1)
+    pr55 = np.concatenate([g["pr_joints"], 7 * np.ones(g["pr_joints"].shape[:2] + (33, 3), np.float32)], 2)
+    assert float(lvd_symmetric(torch.from_numpy(gt55), torch.from_numpy(pr55))) == got
+    import pytest
+    with pytest.raises(IndexError):
+        lvd_symmetric(torch.from_numpy(g["gt_joints"][:, :20]), torch.from_numpy(g["pr_joints"][:, :, :20]))

@@ -885,13 +885,12 @@ def test_wav_in_code_stability(hip, tmp_path):
                                  {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}, {"TS_CHAIN_PERSIST": "1", "TS_WITH_CLIPS": "1"}],
                          ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
                               "row_major_operands", "projections_in_column0", "projections_in_column1",
-                              "split_k_kernels_only", "wide_kernel_everywhere", "persistent_chain_kernel"])
+                              "split_k_kernels_only", "wide_kernel_everywhere"])
 def test_alternate_kernel_paths(hip, env):
     """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
     launches, the 32-column kernel), row-major instead of tiled operands, two placements of the next-row projections, and
     the 64 x 64 wide kernel that coalesced passes use for launches of >= 160 workgroups (forced off / forced onto every
-    launch of >= 64 clips here, small head / column-1 launches included), and the opt-in persistent kernel that runs the whole
-    chain of a 128- / 256-clip pass as one launch with XCD-local barriers (skinny_persist.hip).  The knobs are read once per process, so the
+    launch of >= 64 clips here, small head / column-1 launches included).  The knobs are read once per process, so the
     golden-vector tests are re-run in a child process with each path forced: all must stay bit-exact on the codes."""
     import subprocess
     import sys
@@ -978,6 +977,11 @@ def test_evaluation_reductions_vs_reference_values(hip, golden):
     gs = golden("lvd_symmetric")                                      # the reference's symmetrical=True value (its `~mask.long()` included)
     for key, pr in (("lvd_sym", gs["pr_joints"]), ("lvd_sym_long", gs["pr_long"])):
         np.testing.assert_allclose(M.LVD(torch.from_numpy(gs["gt_joints"]), torch.from_numpy(pr), symmetrical=True).item(), gs[key], rtol=2e-5)
+    # one sample (3-D pr): the reference ignores `symmetrical` there and needs equal lengths (`metrics.py:80-94`)
+    one = torch.from_numpy(gs["pr_joints"][0])
+    assert M.LVD(torch.from_numpy(gs["gt_joints"]), one, symmetrical=True).item() == M.LVD(torch.from_numpy(gs["gt_joints"]), one).item()
+    with pytest.raises(RuntimeError):
+        M.LVD(torch.from_numpy(gs["gt_joints"]), torch.from_numpy(gs["pr_long"][0]))
     np.testing.assert_allclose(M.LVD(torch.from_numpy(gs["gt_joints"]), torch.from_numpy(gs["pr_joints"])).item(), gs["lvd_plain"], rtol=2e-5)
     with pytest.raises(NotImplementedError):
         M.LVD(torch.from_numpy(gs["gt_joints"]), torch.from_numpy(gs["pr_joints"]), weight=True)

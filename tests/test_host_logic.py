@@ -16,12 +16,18 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     from talkshow_amd import _lib
-    hdr = open(os.path.join(REPO, "include", "talkshow_hip.h")).read()
-    declared = set(re.findall(r"\b(ts_[a-z0-9_]+)\s*\(", hdr))
+    import glob
+    headers = sorted(glob.glob(os.path.join(REPO, "include", "*.h")))           # the drop-in ABI and the debug / tuning header
+    assert [os.path.basename(h) for h in headers] == ["talkshow_hip.h", "talkshow_hip_debug.h"]
+    declared = set()
+    for h in headers:
+        declared |= set(re.findall(r"\b(ts_[a-z0-9_]+)\s*\(", open(h).read()))
     declared -= {"ts_tensor"}
+    public = set(re.findall(r"\b(ts_[a-z0-9_]+)\s*\(", open(headers[0]).read()))
+    assert not [n for n in public if n.startswith("ts_debug_")], "debug entry points belong in talkshow_hip_debug.h"
     lib = _lib.load()                       # raises if the .so is missing: there is no fallback
     for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in include/talkshow_hip.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype"
     assert lib.ts_version().decode().startswith("talkshow_hip")
     # no compute without a GPU: asking for a context must fail loudly, not fall back

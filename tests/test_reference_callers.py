@@ -3,7 +3,7 @@
 `oracle/build_ref_callers.py` compiles `init_model` / `infer` of the reference's `scripts/demo.py`, `init_model` / `body_loss` /
 `test` of `scripts/test_body.py` and the two helper modules they import (`data_utils/lower_body.py`, `data_utils/get_j.py`) into
 code objects under `oracle/_ref/` (git-ignored, built where /root/reference exists, travels to the GPU box like a built
-`.so`).  Here those code objects run unchanged with THIS repo's `nets` / `evaluation` / SMPL-X layer bound to the names the
+`.so`; one raw-marshal `.code` file per unit + a JSON manifest of sha256 hashes that `load()` verifies before unmarshalling).  Here those code objects run unchanged with THIS repo's `nets` / `evaluation` / SMPL-X layer bound to the names the
 scripts import — `demo.py --infer --num_sample 2` and `test_body.py`'s test loop — and their results are checked against
 reference goldens and the oracles.  Stubbed, as they are outside the path: the phoneme `Wav2Vec2Processor` download, the
 renderer, `np.save`'s target file, the dataset loader, and `librosa.onset` (third-party, absent).
@@ -29,7 +29,7 @@ from oracle import talkshow_oracle as O      # noqa: E402
 def _units():
     got = BRC.load()
     if got is None:
-        pytest.skip("oracle/_ref/reference_callers.bin is absent (python oracle/build_ref_callers.py where /root/reference exists; "
+        pytest.skip("oracle/_ref/reference_callers.json is absent (python oracle/build_ref_callers.py where /root/reference exists; "
                     "__graft_entry__.build() does it)")
     return got
 
@@ -42,8 +42,9 @@ def test_reference_callers_build_here():
     BRC.build()
     units, meta = BRC.load()
     assert set(units) == {"demo", "test_body", "lower_body", "get_j"}
-    for rel, sha in meta["files"].items():
-        assert hashlib.sha256(open(os.path.join(BRC.REF, rel), "rb").read()).hexdigest() == sha
+    for unit, ent in meta["units"].items():
+        assert hashlib.sha256(open(os.path.join(BRC.REF, ent["file"]), "rb").read()).hexdigest() == ent["source_sha256"]
+        assert hashlib.sha256(open(os.path.join(BRC.OUT_DIR, unit + ".code"), "rb").read()).hexdigest() == ent["code_sha256"]
     ns = {}
     exec(units["lower_body"], ns)
     assert callable(ns["part2full"]) and callable(ns["poses2pred"])
@@ -53,6 +54,39 @@ def test_reference_callers_build_here():
             for f in fs:
                 if f.endswith(".py"):
                     assert "build_ref_callers" not in open(os.path.join(dp, f)).read()
+
+
+def test_reference_callers_integrity_is_checked(tmp_path):
+    """a built unit that does not hash to its manifest entry is refused before it is unmarshalled, a manifest that names
+    other units / files than `UNITS` is refused, and nothing in the load path unpickles anything."""
+    import marshal
+    src = open(BRC.__file__).read()
+    assert "pickle" not in src.replace("no pickle", "").replace("The pickle of earlier rounds".lower(), "").replace("# the pickle of earlier rounds", "")
+    code = compile("x = 1", "<t>", "exec")
+    blob = marshal.dumps(code)
+    man = {"python": list(sys.version_info[:2]), "units": {}}
+    for unit, (rel, names) in BRC.UNITS.items():
+        (tmp_path / (unit + ".code")).write_bytes(blob)
+        man["units"][unit] = {"file": rel, "names": names, "source_sha256": "0" * 64, "code_sha256": BRC._sha(blob), "code_bytes": len(blob)}
+    keep_ref, BRC.REF = BRC.REF, str(tmp_path / "no_reference_here")
+    try:
+        (tmp_path / "reference_callers.json").write_text(json.dumps(man))
+        units, _ = BRC.load(str(tmp_path))
+        assert set(units) == set(BRC.UNITS)
+        (tmp_path / "demo.code").write_bytes(blob + b"\x00")                          # tampered: one byte more
+        with pytest.raises(BRC.RefCallersError, match="does not hash"):
+            BRC.load(str(tmp_path))
+        (tmp_path / "demo.code").write_bytes(blob)
+        man["units"]["demo"]["file"] = "scripts/other.py"                              # a manifest that redirects a unit
+        (tmp_path / "reference_callers.json").write_text(json.dumps(man))
+        with pytest.raises(BRC.RefCallersError, match="does not match"):
+            BRC.load(str(tmp_path))
+        man["python"] = [2, 7]
+        (tmp_path / "reference_callers.json").write_text(json.dumps(man))
+        assert BRC.load(str(tmp_path)) is None                                         # another interpreter's code objects: not loaded
+        assert BRC.load(str(tmp_path / "empty")) is None
+    finally:
+        BRC.REF = keep_ref
 
 
 class _SaveRecorder:
