@@ -131,6 +131,8 @@ int ts_pixelcnn_graph_stats(ts_pixelcnn *pix, void *stream, int B, int H, int mo
 /* state_dict of the reference Generator (keys "audio_encoder.*", "audio_feature_map.*", "audio_middle.*", "decoder.*",
  * "final_out.*"; the positional conv's weight norm is accepted under both the transformers>=4.3x names
  * "...conv.parametrizations.weight.original0/1" and the 4.22-era "...conv.weight_g/_v"). */
+/* num_classes == 0 builds Generator(identity=False) (what smplx_face.py:37-45 constructs when convert_to_6d is set): no id_mlp keys,
+ * first_net over the 256 audio channels alone, a 6-wide jaw head -> ts_face_generate writes (B,frames,106) and ignores id_dev. */
 int ts_face_create(ts_ctx *ctx, const ts_tensor *sd, int n, int n_layers, int num_classes, ts_face **out);
 void ts_face_destroy(ts_face *face);
 /* Generator.forward, eval (s2g_face.py:196-224; TrainWrapper.generate / infer_on_audio, smplx_face.py:169-238):

@@ -9,7 +9,7 @@ import torch
 
 from nets.base import TrainWrapperBaseClass, resolve_device
 from talkshow_amd.modules import AE as s2g_body
-from talkshow_amd.pose_index import c_index_3d
+from talkshow_amd.pose_index import c_index_3d, c_index_6d
 
 
 class TrainWrapper(TrainWrapperBaseClass):
@@ -21,14 +21,12 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.gan = False
         self.convert_to_6d, self.expression = pose_cfg.convert_to_6d, pose_cfg.expression
         self.preleng = getattr(pose_cfg, 'pre_pose_length', 0)
-        if self.convert_to_6d:
-            raise NotImplementedError("convert_to_6d=true is not used by any shipped config (SURVEY.md §2)")
         self.init_params()
         self.num_classes = 4
         self.g = s2g_body(self.each_dim[1] + self.each_dim[2], embedding_dim=64, num_embeddings=0, num_hiddens=1024,
                           num_residual_layers=2, num_residual_hiddens=512).to(self.device)
         self.discriminator = None
-        self.c_index = c_index_3d
+        self.c_index = c_index_6d if self.convert_to_6d else c_index_3d   # `body_ae.py:50-53`
         super().__init__(args, config)
 
     def init_optimizer(self):

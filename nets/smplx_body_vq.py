@@ -7,7 +7,7 @@ from nets.base import TrainWrapperBaseClass, resolve_device
 from nets.utils import denormalize
 from talkshow_amd import _lib
 from talkshow_amd.modules import VQVAE as s2g_body
-from talkshow_amd.pose_index import c_index_3d
+from talkshow_amd.pose_index import c_index_3d, c_index_6d
 
 
 class TrainWrapper(TrainWrapperBaseClass):
@@ -17,8 +17,6 @@ class TrainWrapper(TrainWrapperBaseClass):
         self.device = resolve_device(args.gpu)
         self.global_step = self.epoch = 0
         self.convert_to_6d, self.expression = pose_cfg.convert_to_6d, pose_cfg.expression
-        if self.convert_to_6d:
-            raise NotImplementedError("convert_to_6d=true is not used by any shipped config (SURVEY.md §2)")
         self.init_params()
         self.num_classes = 4
         self.composition = model_cfg.composition
@@ -30,7 +28,7 @@ class TrainWrapper(TrainWrapperBaseClass):
         else:                    # one VQ-VAE over all 129 dims, `:45-46`
             self.g = s2g_body(self.each_dim[1] + self.each_dim[2], **vq_kw).to(self.device)
         self.discriminator = None
-        self.c_index = c_index_3d
+        self.c_index = c_index_6d if self.convert_to_6d else c_index_3d   # `smplx_body_vq.py:50-53`: 78 + 180 modelled dims in the 6-D form
         super().__init__(args, config)
 
     def init_optimizer(self):

@@ -78,6 +78,7 @@ void params_for(const ConvLayer &L, const float *x, int ldx, int B, int Lin, int
 struct ts_face {
     ts_ctx *ctx = nullptr;
     int NL = 12, HID = 768, HEADS = 12, FFN = 3072, C0 = 512, NCLS = 4, POSK = 128, POSG = 16;
+    int JAW = 3, CIN = 320;   // identity=False (num_classes 0, the reference's convert_to_6d form): no id channels (CIN 256), 6 jaw values
     DevBuf c0_w, c0_g, c0_b;
     ConvLayer fc[6];
     int fc_k[6] = {3, 3, 3, 3, 2, 2};
@@ -114,7 +115,12 @@ int ts_face_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int n_layers, int n
     std::unique_ptr<ts_face> f(new ts_face());
     f->ctx = ctx;
     f->NL = n_layers;
+    if (num_classes < 0) return fail("ts_face_create: num_classes < 0");
     f->NCLS = num_classes;
+    // Generator(identity=False) (s2g_face.py:142-171, built by smplx_face.py:37-45 when convert_to_6d is set): AudioEncoder without
+    // id_mlp (first_net takes the 256 audio channels alone), jaw head each_dim[0] = 6 wide (one joint in the 6-D rotation form)
+    f->JAW = num_classes > 0 ? 3 : 6;
+    f->CIN = num_classes > 0 ? 320 : 256;
     const int C0 = f->C0, HID = f->HID, FFN = f->FFN;
     const std::string p = "audio_encoder.";
     // ---- feature extractor ----
@@ -193,13 +199,16 @@ int ts_face_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int n_layers, int n
     }
     // ---- heads ----
     TS_TRY(load_linear(sd, "audio_feature_map", 256, HID, 0, &f->afm));
-    const float *iw = sd.get("audio_middle.id_mlp.weight", {64, num_classes, 1}), *ib = sd.get("audio_middle.id_mlp.bias", {64});
-    if (!iw || !ib) return 1;
-    TS_TRY(up(f->id_w, iw, (size_t)64 * num_classes));
-    TS_TRY(up(f->id_b, ib, 64));
+    if (num_classes > 0) {
+        const float *iw = sd.get("audio_middle.id_mlp.weight", {64, num_classes, 1}), *ib = sd.get("audio_middle.id_mlp.bias", {64});
+        if (!iw || !ib) return 1;
+        TS_TRY(up(f->id_w, iw, (size_t)64 * num_classes));
+        TS_TRY(up(f->id_b, ib, 64));
+    }
     const std::string fn = "audio_middle.first_net.conv_layers.";
-    TS_TRY(load_conv3(sd, fn + "0.residual_layer.0", 256, 320, 3, &f->fn0res));
-    TS_TRY(load_conv3(sd, fn + "0.conv", 256, 320, 3, &f->fn[0]));
+    // 320 -> 256 channels: the residual branch is a conv; 256 -> 256 (identity=False): nn.Identity, no keys (layers.py:95-96)
+    if (f->CIN != 256) TS_TRY(load_conv3(sd, fn + "0.residual_layer.0", 256, f->CIN, 3, &f->fn0res));
+    TS_TRY(load_conv3(sd, fn + "0.conv", 256, f->CIN, 3, &f->fn[0]));
     TS_TRY(load_conv3(sd, fn + "1.conv", 256, 256, 3, &f->fn[1]));
     TS_TRY(load_conv3(sd, fn + "2.conv", 256, 256, 3, &f->fn[2]));
     for (int i = 0; i < 3; ++i) TS_TRY(load_ln(sd, fn + std::to_string(i) + ".norm", 256, &f->fn_ln[i]));
@@ -210,7 +219,7 @@ int ts_face_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int n_layers, int n
             TS_TRY(load_conv3(sd, k + ".conv", c, i == 0 ? 256 : c, 3, &f->dec[d][i]));
             TS_TRY(load_ln(sd, k + ".norm", c, &f->dec_ln[d][i]));
         }
-        TS_TRY(load_conv3(sd, "final_out." + std::to_string(d), d == 0 ? 3 : 100, c, 1, &f->fin[d]));
+        TS_TRY(load_conv3(sd, "final_out." + std::to_string(d), d == 0 ? f->JAW : 100, c, 1, &f->fin[d]));
     }
     *out = f.release();
     return 0;
@@ -231,9 +240,10 @@ int ts_face_set_arith(ts_face *f, int bf16_products) {
 
 // s2g_face.Generator.forward, eval (s2g_face.py:196-224): wav (B,N) fp32, id (B,num_classes) fp32 (one-hot or zeros,
 // smplx_face.py:205-208) -> out (B,frames,103); hidden_out optional (B,frames,768) = wav2vec2 last_hidden_state.
+// A handle created with num_classes = 0 is Generator(identity=False): id is ignored (may be NULL), out is (B,frames,106).
 int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, const float *id, float *out, float *hidden_out,
                      void *stream) {
-    if (!f || !wav || !id || !out) return fail("ts_face_generate: null argument");
+    if (!f || !wav || !out || (!id && f->NCLS > 0)) return fail("ts_face_generate: null argument");
     if (B < 1 || frames < 1) return fail("ts_face_generate: bad shape");
     hipStream_t s = (hipStream_t)stream;
     ts_ctx *ctx = f->ctx;
@@ -266,6 +276,7 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
     TS_TRY(w.ATT.ensure(M * HID * F));
     TS_TRY(w.FF.ensure(M * FFN * F));
     TS_TRY(w.X320.ensure(M * 320 * F));
+    const int CIN = f->CIN, JAW = f->JAW, OUTW = f->JAW + 100;
     TS_TRY(w.Y1.ensure(M * 256 * F));
     TS_TRY(w.Y2.ensure(M * 256 * F));
     TS_TRY(w.R.ensure(M * 256 * F));
@@ -374,15 +385,15 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
     }
     if (hidden_out) TS_HIP(hipMemcpyAsync(hidden_out, w.H.f(), M * HID * F, hipMemcpyDeviceToDevice, s));
     // ---- audio_feature_map | id channels ----
-    TS_TRY(conv(f->afm, w.H.f(), HID, 1, (int)M, (int)M, 1, nullptr, 0, w.X320.f(), 320, 0, 256, 0));
-    {
+    TS_TRY(conv(f->afm, w.H.f(), HID, 1, (int)M, (int)M, 1, nullptr, 0, w.X320.f(), CIN, 0, 256, 0));
+    if (f->NCLS > 0) {
         MiscScope ms(ctx, s);
         TS_HIP(launch_fill_id(id, f->NCLS, f->id_w.f(), f->id_b.f(), 64, w.X320.f(), 320, 256, B, T, s));
     }
     // ---- SeqTranslator1D: 3 x {conv, LN, + residual, ReLU} ----
-    TS_TRY(conv(f->fn[0], w.X320.f(), 320, B, T, T, 1, nullptr, 0, w.Y1.f(), 256, 0, 256, 0));
-    TS_TRY(conv(f->fn0res, w.X320.f(), 320, B, T, T, 1, nullptr, 0, w.R.f(), 256, 0, 256, 0));
-    TS_TRY(ln(w.Y1.f(), 256, f->fn_ln[0], w.R.f(), 1, w.Y2.f()));
+    TS_TRY(conv(f->fn[0], w.X320.f(), CIN, B, T, T, 1, nullptr, 0, w.Y1.f(), 256, 0, 256, 0));
+    if (CIN != 256) TS_TRY(conv(f->fn0res, w.X320.f(), CIN, B, T, T, 1, nullptr, 0, w.R.f(), 256, 0, 256, 0));
+    TS_TRY(ln(w.Y1.f(), 256, f->fn_ln[0], CIN != 256 ? w.R.f() : w.X320.f(), 1, w.Y2.f()));
     TS_TRY(conv(f->fn[1], w.Y2.f(), 256, B, T, T, 1, nullptr, 0, w.Y1.f(), 256, 0, 256, 0));
     TS_TRY(ln(w.Y1.f(), 256, f->fn_ln[1], w.Y2.f(), 1, w.R.f()));
     TS_TRY(conv(f->fn[2], w.R.f(), 256, B, T, T, 1, nullptr, 0, w.Y1.f(), 256, 0, 256, 0));
@@ -394,7 +405,7 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
     TS_TRY(ln(w.D1.f(), 64, f->dec_ln[0][1], nullptr, 1, w.D2.f()));
     TS_TRY(conv(f->dec[0][2], w.D2.f(), 64, B, T, T, 1, nullptr, 0, w.D1.f(), 64, 0, 64, 0));
     TS_TRY(ln(w.D1.f(), 64, f->dec_ln[0][2], nullptr, 1, w.D2.f()));
-    TS_TRY(conv(f->fin[0], w.D2.f(), 64, 1, (int)M, (int)M, 1, nullptr, 0, out, 103, 0, 3, 0));
+    TS_TRY(conv(f->fin[0], w.D2.f(), 64, 1, (int)M, (int)M, 1, nullptr, 0, out, OUTW, 0, JAW, 0));
     // ---- expression head (256 ch) ----
     TS_TRY(conv(f->dec[1][0], w.Y2.f(), 256, B, T, T, 1, nullptr, 0, w.Y1.f(), 256, 0, 256, 0));
     TS_TRY(ln(w.Y1.f(), 256, f->dec_ln[1][0], nullptr, 1, w.R.f()));
@@ -402,7 +413,7 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
     TS_TRY(ln(w.Y1.f(), 256, f->dec_ln[1][1], nullptr, 1, w.R.f()));
     TS_TRY(conv(f->dec[1][2], w.R.f(), 256, B, T, T, 1, nullptr, 0, w.Y1.f(), 256, 0, 256, 0));
     TS_TRY(ln(w.Y1.f(), 256, f->dec_ln[1][2], nullptr, 1, w.R.f()));
-    TS_TRY(conv(f->fin[1], w.R.f(), 256, 1, (int)M, (int)M, 1, nullptr, 0, out, 103, 3, 100, 0));
+    TS_TRY(conv(f->fin[1], w.R.f(), 256, 1, (int)M, (int)M, 1, nullptr, 0, out, OUTW, JAW, 100, 0));
     return 0;
 }
 

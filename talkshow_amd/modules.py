@@ -436,11 +436,15 @@ class FaceGenerator(NativeModule):
 
     def __init__(self, n_poses=88, each_dim=None, dim_list=None, training=False, device=None, identity=True,
                  num_classes=4, n_layers=12):
-        if not identity:
-            raise NotImplementedError("identity=False (convert_to_6d) is not used by any shipped config")
-        self.num_classes, self.n_layers = num_classes, n_layers
+        # identity=False is what the reference wrapper builds when convert_to_6d is set (`smplx_face.py:37-45`): no id channels,
+        # jaw head each_dim[0] wide (6)
+        self.identity, self.num_classes, self.n_layers = bool(identity), num_classes, n_layers
+        self.jaw_dim = int(each_dim[0]) if each_dim else (3 if identity else 6)
+        if self.jaw_dim != (3 if identity else 6):
+            raise NotImplementedError(f"jaw head of width {self.jaw_dim} with identity={identity}: the reference pairs 3 with True, 6 with False")
+        self.out_dim = self.jaw_dim + 100
         self.device = device
-        super().__init__(synth.face_state_dict(0, n_layers=n_layers, num_classes=num_classes))
+        super().__init__(synth.face_state_dict(0, n_layers=n_layers, num_classes=num_classes, identity=self.identity, jaw_dim=self.jaw_dim))
 
     def load_state_dict(self, sd, strict=True):
         # checkpoints written with transformers 4.22 (the reference's pin) spell the weight-normed positional conv
@@ -455,7 +459,7 @@ class FaceGenerator(NativeModule):
     def _create(self, ctx):
         arr, n, keep = _lib.pack_state_dict(self._sd)
         h = C.c_void_p()
-        _lib.check(_lib.load().ts_face_create(ctx, arr, n, self.n_layers, self.num_classes, C.byref(h)))
+        _lib.check(_lib.load().ts_face_create(ctx, arr, n, self.n_layers, self.num_classes if self.identity else 0, C.byref(h)))
         return h
 
     def _destroy(self, h):
@@ -468,14 +472,17 @@ class FaceGenerator(NativeModule):
         return self
 
     def run(self, wav, id_vec, frames, want_hidden=False):
-        """wav (B,N) device fp32, id_vec (B,num_classes) -> (B,frames,103) [, hidden (B,frames,768)]."""
+        """wav (B,N) device fp32, id_vec (B,num_classes) -> (B,frames,103) [, hidden (B,frames,768)]; (B,frames,106) for identity=False."""
         dev = self._dev()
         wav = _dev_f32(wav, dev)
         B, N = wav.shape
-        id_vec = _dev_f32(id_vec, dev).reshape(-1, self.num_classes)
-        if id_vec.shape[0] == 1 and B > 1:
-            id_vec = id_vec.repeat(B, 1).contiguous()
-        out = torch.empty((B, frames, 103), dtype=torch.float32, device=dev)
+        if self.identity:
+            id_vec = _dev_f32(id_vec, dev).reshape(-1, self.num_classes)
+            if id_vec.shape[0] == 1 and B > 1:
+                id_vec = id_vec.repeat(B, 1).contiguous()
+        else:
+            id_vec = None                                    # Generator(identity=False) never looks at it
+        out = torch.empty((B, frames, self.out_dim), dtype=torch.float32, device=dev)
         hid = torch.empty((B, frames, 768), dtype=torch.float32, device=dev) if want_hidden else None
         _lib.check(_lib.load().ts_face_generate(self.handle(), _lib.dptr(wav), B, N, int(frames), _lib.dptr(id_vec),
                                                 _lib.dptr(out), _lib.dptr(hid), _lib.stream_ptr()))

@@ -171,7 +171,7 @@ def pixelcnn_state_dict(seed=0, input_dim=2048, dim=256, n_layers=15, n_classes=
 
 
 def face_state_dict(seed=0, n_layers=12, hidden=768, heads=12, ffn=3072, conv_dim=512, num_classes=4,
-                    pos_k=128, pos_groups=16, legacy_weight_norm_keys=False):
+                    pos_k=128, pos_groups=16, legacy_weight_norm_keys=False, identity=True, jaw_dim=3):
     """`s2g_face.Generator` (`nets/spg/s2g_face.py:142-224`) around the HF wav2vec2-base architecture
     (`nets/spg/wav2vec.py:73-143`; key names of transformers >= 4.3x; `legacy_weight_norm_keys=True` emits the
     4.22-era `weight_g` / `weight_v` names the reference's own checkpoints carry)."""
@@ -211,16 +211,19 @@ def face_state_dict(seed=0, n_layers=12, hidden=768, heads=12, ffn=3072, conv_di
         lin(q + "feed_forward.output_dense", hidden, ffn, 1.2)
         ln(q + "final_layer_norm", hidden)
     lin("audio_feature_map", 256, hidden)
-    b.normal("audio_middle.id_mlp.weight", (64, num_classes, 1), 0.7)
-    b.normal("audio_middle.id_mlp.bias", (64,), 0.1)
+    if identity:
+        b.normal("audio_middle.id_mlp.weight", (64, num_classes, 1), 0.7)
+        b.normal("audio_middle.id_mlp.bias", (64,), 0.1)
+    cin = 320 if identity else 256      # `identity=False` (the convert_to_6d form, `s2g_face.py:107-113`): no id channels
 
     def conv(prefix, cout, cin, k, gain=1.3):
         b.normal(prefix + ".weight", (cout, cin, k), gain / np.sqrt(cin * k))
         b.normal(prefix + ".bias", (cout,), 0.05)
 
     fn = "audio_middle.first_net.conv_layers."
-    conv(fn + "0.residual_layer.0", 256, 320, 3, 0.8)
-    conv(fn + "0.conv", 256, 320, 3)
+    if cin != 256:                      # equal widths: the residual branch is nn.Identity (`layers.py:95-96`), no keys
+        conv(fn + "0.residual_layer.0", 256, cin, 3, 0.8)
+    conv(fn + "0.conv", 256, cin, 3)
     ln(fn + "0.norm", 256)
     for i in (1, 2):
         conv(fn + f"{i}.conv", 256, 256, 3)
@@ -234,7 +237,7 @@ def face_state_dict(seed=0, n_layers=12, hidden=768, heads=12, ffn=3072, conv_di
         for i in range(3):
             conv(f"decoder.{d}.{i}.conv", c, c0 if i == 0 else c, 3)
             ln(f"decoder.{d}.{i}.norm", c)
-    conv("final_out.0", 3, 64, 1, 0.3)
+    conv("final_out.0", jaw_dim, 64, 1, 0.3)
     conv("final_out.1", 100, 256, 1, 0.3)
     return b.sd
 

@@ -296,6 +296,40 @@ def main():
                         f"margin_{part}": mg.astype(np.float32), f"recon2_{part}": rec.numpy()})
         save("vq_encode_b32", gt_seed=np.asarray([gt_seed, B, Tn]), **out)
 
+    # ---- 4d. convert_to_6d=true through the reference wrappers s2g_body_vq (78 + 180 modelled dims, c_index_6d over 330-wide rows,
+    # `smplx_body_vq.py:50-53`) and s2g_body_ae (`body_ae.py:50-53`): no shipped config uses it, the wrappers support it
+    if want("wrappers_6d"):
+        from trainer.config import Object
+        from data_utils.lower_body import c_index_6d
+        targs = argparse.Namespace(gpu="cpu", infer=True)
+        B, Tn = 2, 24
+        vcfg = json.load(open(os.path.join(REF, "config/body_vq.json")))
+        vcfg["Data"]["pose"]["convert_to_6d"] = True
+        w = quiet(nets.s2g_body_vq, targs, Object(vcfg))
+        sd_b = synth.vqvae_state_dict(seed=9, in_dim=78)
+        sd_h = synth.vqvae_state_dict(seed=9, in_dim=180, salt=1)
+        w.load_state_dict({"g_body": T(sd_b), "g_hand": T(sd_h)})
+        p258 = synth.gt_poses(26, B, Tn, dim=258)
+        full = np.zeros((B, 330, Tn), np.float32)
+        full[:, c_index_6d, :] = p258.transpose(0, 2, 1)
+        out = quiet(w.infer_on_audio, torch.zeros(B, 64, Tn), initial_pose=torch.from_numpy(full), id=torch.tensor([0]), fps=30)
+        with torch.no_grad():
+            _, lat_b = w.g_body.encode(gt_poses=torch.from_numpy(np.ascontiguousarray(p258[..., :78])))
+            _, lat_h = w.g_hand.encode(gt_poses=torch.from_numpy(np.ascontiguousarray(p258[..., 78:])))
+        cfg = json.load(open(os.path.join(REF, "config/body_pixel.json")))
+        cfg["Data"]["pose"]["convert_to_6d"] = True
+        a = quiet(nets.s2g_body_ae, targs, Object(cfg))
+        a.load_state_dict({"g": T(synth.ae_state_dict(seed=9, in_dim=258))})
+        wide = np.zeros((B, Tn, 330), np.float32)
+        wide[:, :, c_index_6d] = p258
+        a.g.eval()
+        with torch.no_grad():
+            feat, x258 = a.extract(torch.from_numpy(wide))
+        assert torch.equal(x258, torch.from_numpy(p258))
+        print("wrappers_6d: vq out", out.shape, "std", float(out.std()), "ae feat", tuple(feat.shape), "std", float(feat.std()))
+        save("wrappers_6d", poses258=p258, vq_out=out, vq_codes=np.stack([lat_b.numpy(), lat_h.numpy()], -1), ae_feat=feat.numpy(),
+             c_index=np.asarray(c_index_6d))
+
     # ---- 5. face generator over the installed transformers wav2vec2 (reference: s2g_face.Generator + wav2vec.py) ----
     if want("face_full"):
         fcfg = json.load(open(os.path.join(REF, "config/face.json")))
@@ -316,6 +350,25 @@ def main():
             gen = w.generate(torch.from_numpy(wav)[:, None, :], frame)      # smplx_face.py:221-238 (zero id)
         print("face_full: out", tuple(out.shape), "std", float(out.std()), "hidden std", float(hs.std()))
         save("face_full", wav=wav, ids=ids.numpy(), out=out.numpy(), hidden=hs.numpy(), generate_zero_id=gen.numpy())
+
+    # ---- 5a. the face wrapper with convert_to_6d=true: Generator(identity=False) — no id channels, 6-wide jaw head (`smplx_face.py:37-45`,
+    # `s2g_face.py:107-113`); 2 s clips like face_full
+    if want("face_6d"):
+        fcfg = json.load(open(os.path.join(REF, "config/face.json")))
+        fcfg["Data"]["pose"]["convert_to_6d"] = True
+        from trainer.config import Object
+        w = quiet(nets.s2g_face, argparse.Namespace(gpu="cpu", infer=True), Object(fcfg))
+        assert w.generator.identity is False and w.each_dim[0] == 6
+        w.load_state_dict({"generator": T(synth.face_state_dict(seed=8, identity=False, jaw_dim=6))})     # strict: pins the key set
+        B, N = 2, 32000
+        wav = synth.wav16(35, B, N)
+        w.generator.eval()
+        with torch.no_grad():
+            out = w.infer_on_audio(torch.from_numpy(wav)[:, None, :], id=torch.tensor([1, 2]))
+            gen = w.generate(torch.from_numpy(wav)[:, None, :], N * 30 // 16000)
+        assert np.array_equal(out, gen.numpy())                                  # the id is not looked at
+        print("face_6d: out", out.shape, "std", float(out.std()))
+        save("face_6d", wav_seed=np.asarray([35, B, N]), out=out)
 
     # ---- 5b. the face generator at BASELINE length: two full 10 s clips (160 000 samples -> 499 conv frames -> 300 output frames)
     if want("face_10s"):

@@ -539,6 +539,42 @@ def test_wrapper_body_ae_extract(hip, golden, tmp_path):
     assert len(w.state_dict()["g"]) == 210                                      # the reference AE's key count
 
 
+def test_wrappers_convert_to_6d_vs_reference(hip, golden, tmp_path):
+    """`convert_to_6d=true` through `nets.s2g_body_vq` (`smplx_body_vq.py:50-53`: 78 + 180 modelled dims gathered by `c_index_6d` from
+    330-wide rows) and `nets.s2g_body_ae` (`body_ae.py:50-53`) against what the reference's own wrappers returned
+    (tests/golden/make_golden.py --only wrappers_6d).  No shipped config uses the branch; the drop-in supports it as the reference does."""
+    from nets.init_model import init_model
+    from talkshow_amd.config import Object
+    from talkshow_amd.pose_index import c_index_6d
+    g = golden("wrappers_6d")
+    assert np.array_equal(g["c_index"], c_index_6d)
+    args = argparse.Namespace(gpu=0, infer=True)
+    vcfg = json.load(open(os.path.join(REPO, "config", "body_vq.json")))
+    vcfg["Data"]["pose"]["convert_to_6d"] = True
+    w = init_model("s2g_body_vq", args, Object(vcfg))
+    assert w.each_dim[1:3] == [78, 180] and len(w.c_index) == 258
+    w.load_state_dict({"g_body": synth.to_torch(synth.vqvae_state_dict(seed=9, in_dim=78)),
+                       "g_hand": synth.to_torch(synth.vqvae_state_dict(seed=9, in_dim=180, salt=1))})
+    B, T = g["poses258"].shape[:2]
+    full = np.zeros((B, 330, T), np.float32)
+    full[:, c_index_6d, :] = g["poses258"].transpose(0, 2, 1)
+    out = w.infer_on_audio(torch.zeros(B, 64, T), initial_pose=torch.from_numpy(full), id=torch.tensor([0]), fps=30)
+    assert out.shape == g["vq_out"].shape == (T, B * 258)
+    np.testing.assert_allclose(out, g["vq_out"], atol=1e-4, rtol=0)
+    codes, _ = w.reconstruct_batch(g["poses258"])
+    np.testing.assert_array_equal(codes.cpu().numpy(), g["vq_codes"])
+    cfg = json.load(open(os.path.join(REPO, "config", "body_pixel.json")))
+    cfg["Data"]["pose"]["convert_to_6d"] = True
+    cfg["Model"]["vq_path"] = str(tmp_path / "unused.pth")
+    a = init_model("s2g_body_ae", args, Object(cfg))
+    a.load_state_dict({"g": synth.to_torch(synth.ae_state_dict(seed=9, in_dim=258))})
+    wide = np.zeros((B, T, 330), np.float32)
+    wide[:, :, c_index_6d] = g["poses258"]
+    feat, x258 = a.extract(torch.from_numpy(wide))
+    np.testing.assert_array_equal(x258.cpu().numpy(), g["poses258"])
+    np.testing.assert_allclose(feat.cpu().numpy(), g["ae_feat"], atol=2e-5, rtol=0)
+
+
 # ----------------------------------------------------------------------------------------------- full-size properties
 def test_full_size_properties(hip, tmp_path):
     """BASELINE batch (32 clips x 10 s): determinism, batch-composition independence, encode(decode) idempotence."""
@@ -685,6 +721,26 @@ def test_wrapper_face(hip, golden, tmp_path):
     ref = FO.face_generator(wav, np.eye(4, dtype=np.float32)[[3]], synth.face_state_dict(seed=7), frame)
     np.testing.assert_allclose(out, ref, atol=1e-4, rtol=0)
     assert w.each_dim == [3, 72, 90, 100]
+
+
+def test_wrapper_face_convert_to_6d_vs_reference(hip, golden):
+    """`nets.s2g_face` with `convert_to_6d=true` builds `Generator(identity=False)` (`smplx_face.py:37-45`): no id channels, identity
+    residual in the first LN-conv, a 6-wide jaw head -> (B, T, 106).  Against the reference wrapper's own output (face_6d golden)."""
+    from nets.init_model import init_model
+    from talkshow_amd.config import Object
+    g = golden("face_6d")
+    seed, B, N = (int(v) for v in g["wav_seed"])
+    cfg = json.load(open(os.path.join(REPO, "config", "face.json")))
+    cfg["Data"]["pose"]["convert_to_6d"] = True
+    w = init_model("s2g_face", argparse.Namespace(gpu=0, infer=True), Object(cfg))
+    assert w.generator.identity is False and w.each_dim[0] == 6
+    w.load_state_dict({"generator": synth.to_torch(synth.face_state_dict(seed=8, identity=False, jaw_dim=6))})
+    wav = torch.from_numpy(synth.wav16(seed, B, N))[:, None, :]
+    out = w.infer_on_audio(wav, id=torch.tensor([1, 2]))
+    assert out.shape == g["out"].shape == (B, N * 30 // 16000, 106)
+    np.testing.assert_allclose(out, g["out"], atol=1e-4, rtol=0)
+    gen = w.generate(wav, N * 30 // 16000)
+    np.testing.assert_array_equal(gen.cpu().numpy(), out)
 
 
 @pytest.mark.parametrize("products,tol_hidden,tol_out", [(6, 1e-4, 1e-4), (3, 1e-4, 1e-4)])
@@ -882,7 +938,7 @@ def test_wav_in_code_stability(hip, tmp_path):
                                  {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"},
                                  {"TS_SKINNY_TILED": "0", "TS_WITH_CLIPS": "1"}, {"TS_PIX_DEFER_P": "0", "TS_WITH_CLIPS": "1"},
                                  {"TS_PIX_DEFER_P": "1", "TS_WITH_CLIPS": "1"}, {"TS_SKINNY_WIDE_MIN": "0", "TS_WITH_CLIPS": "1"},
-                                 {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}, {"TS_CHAIN_PERSIST": "1", "TS_WITH_CLIPS": "1"}],
+                                 {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}],
                          ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
                               "row_major_operands", "projections_in_column0", "projections_in_column1",
                               "split_k_kernels_only", "wide_kernel_everywhere"])
