@@ -149,13 +149,16 @@ def face_block(local):
     _lib.check(lib.ts_prof_enable(ctx, 1))
     m.run(wav, ids, T)
     torch.cuda.synchronize()
-    msf, nf, flf = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
-    _lib.check(lib.ts_prof_read(ctx, msf, nf, flf, 1))
+    msf, nf, flf = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_double * 4)()
+    _lib.check(lib.ts_prof_read_n(ctx, 4, msf, nf, flf, 1))
     _lib.check(lib.ts_prof_enable(ctx, 0))
     ach = flf[0] / (msf[0] * 1e-3) / 1e12
+    ach_a = flf[3] / (msf[3] * 1e-3) / 1e12 if msf[3] > 0 else 0.0
     out = {"workload": "BASELINE configs[2]: face generator, batch=64 x 10 s @16 kHz, 103 params @30 fps",
            "frames_per_s": B * T / dt, "ms_per_batch": dt * 1e3,
            "conv_gemm_f32": {"launches": nf[0], "ms": msf[0], "achieved_TFLOPs": ach, "frac_of_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS},
+           "attention_fused": {"launches": nf[3], "ms": msf[3], "achieved_TFLOPs": ach_a, "frac_of_fp32_mfma_peak": ach_a / PEAK_FP32_MFMA_TFLOPS,
+                               "what": "QK^T -> online soft-max -> PV per (clip, head) in one kernel (csrc/face.hip::attention_kernel), 12 layers"},
            "other_kernels_ms": msf[2]}
     # OPT-IN split-bf16 plans beside the fp32 line (never the headline; dtype of the main line stays f32): speed on the same batch,
     # error of the same two reference-golden clips the parity tests use (tests/golden/face_10s.npz), embedded in a batch of 64

@@ -212,6 +212,9 @@ int ts_assemble_full(ts_ctx *ctx, const float *body_dev, int Tb, const float *fa
  * flops_out[3] (algorithmic 2*M*N*K of the GEMM launches; 0 for family 2). */
 int ts_prof_enable(ts_ctx *ctx, int on);
 int ts_prof_read(ts_ctx *ctx, double *ms_out, int64_t *launches_out, double *flops_out, int reset);
+/* the same with n_families (1..4) entries per array; family 3 = the face generator's fused attention kernel (flops = 4 T^2 64 per
+ * (clip, head) and layer), which ts_prof_read's three families leave out */
+int ts_prof_read_n(ts_ctx *ctx, int n_families, double *ms_out, int64_t *launches_out, double *flops_out, int reset);
 
 /* stage 1 of ts_mfcc_forward alone (get_mfcc_sepa, data_utils/utils.py:234-263, resamples the whole clip and then takes
  * the MFCC of two parts): wav_dev (B,N) at sr_in -> out_dev (B, ts_mfcc_resampled_len(m, N)) at sr_out. */

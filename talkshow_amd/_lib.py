@@ -86,6 +86,7 @@ SIGNATURES = {
     "ts_eval_diversity": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
     "ts_prof_enable": (_i, [_vp, _i]),
     "ts_prof_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _i]),
+    "ts_prof_read_n": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), _i]),
 }
 
 _lib = None

@@ -96,7 +96,7 @@ struct ts_face {
     int split_planes = 0;   // 0: fp32 MFMA (default, the parity path); 2 / 3: opt-in split-bf16 GEMMs (ts_face_set_arith)
 
     struct Work {
-        DevBuf A, Bf, part, stats, X512, H, H2, TMP, QKV, SC, VT, ATT, FF, X320, Y1, Y2, R, D1, D2;
+        DevBuf A, Bf, part, stats, X512, H, H2, TMP, QKV, ATT, FF, X320, Y1, Y2, R, D1, D2;
     };
     StreamWorks<Work> works;
     Work &work(hipStream_t s) { return works.get(s); }
@@ -255,9 +255,7 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
         L[i + 1] = (L[i] - f->fc_k[i]) / 2 + 1;
         if (L[i] < f->fc_k[i]) return fail("ts_face_generate: audio too short (needs >= 400 samples)");
     }
-    const int Tp = round_up(T, 32);
-    if ((long)B * f->HEADS * T * Tp > (1l << 31) - 1 || Tp > 60000)
-        return fail("ts_face_generate: B * heads * frames^2 exceeds the attention score buffer's 2^31 entries: split the call");
+    if ((long)B * f->HEADS > 65535) return fail("ts_face_generate: B * heads exceeds the attention grid (65 535): split the call");
     const long M = (long)B * T;
     ts_face::Work &w = f->work(s);
     const size_t F = sizeof(float);
@@ -271,8 +269,6 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
     TS_TRY(w.H2.ensure(M * HID * F));
     TS_TRY(w.TMP.ensure(M * HID * F));
     TS_TRY(w.QKV.ensure(M * 3 * HID * F));
-    TS_TRY(w.SC.ensure((size_t)B * HEADS * T * Tp * F));
-    TS_TRY(w.VT.ensure((size_t)B * HEADS * 64 * Tp * F));
     TS_TRY(w.ATT.ensure(M * HID * F));
     TS_TRY(w.FF.ensure(M * FFN * F));
     TS_TRY(w.X320.ensure(M * 320 * F));
@@ -350,33 +346,11 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
     for (auto &Lp : f->layers) {
         EncLayer &E = *Lp;
         TS_TRY(conv(E.qkv, w.H.f(), HID, 1, (int)M, (int)M, 1, nullptr, 0, w.QKV.f(), 3 * HID, 0, 3 * HID, 0));
-        // scores[z] = Q_z K_z^T, z = b*heads + h
-        std::memset(&p, 0, sizeof(p));
-        p.M = T; p.Lout = p.Lin = T; p.stride = 1;
-        p.ldx = 3 * HID; p.ldo = Tp; p.N = T; p.Ktot = 64; p.ldw = 3 * HID; p.w_rows = T;
-        p.ngroups = B * HEADS; p.zdiv = HEADS;
-        p.x_zs0 = (long)T * 3 * HID; p.x_zs1 = 64;
-        p.w_zs0 = (long)T * 3 * HID; p.w_zs1 = 64;
-        p.o_zs0 = (long)HEADS * T * Tp; p.o_zs1 = (long)T * Tp;
-        p.g[0].x = w.QKV.f(); p.g[0].w = w.QKV.f() + HID; p.g[0].out = w.SC.f();
-        p.g[0].nseg = 1; p.g[0].seg[0] = ConvSeg{0, 0, 64, 1};
-        TS_TRY(run_conv(ctx, p, 0, s));
+        // softmax(Q K^T / 8) V per (clip, head), fused: the scores stay in registers (face.hip::attention_kernel)
         {
-            MiscScope ms(ctx, s);
-            TS_HIP(launch_softmax_rows(w.SC.f(), (long)B * HEADS * T, T, Tp, 0.125f, s));
-            TS_HIP(launch_transpose_v(w.QKV.f(), B, T, 3 * HID, 2 * HID, HEADS, w.VT.f(), Tp, s));
+            MiscScope ms(ctx, s, FAM_ATTN, 4.0 * B * HEADS * (double)T * T * 64);   // Q K^T and P V: 2 x (2 T^2 d) per (clip, head)
+            TS_HIP(launch_attention(w.QKV.f(), B, T, HID, HEADS, 0.125f, w.ATT.f(), s));
         }
-        // attn[z] = P_z V_z
-        std::memset(&p, 0, sizeof(p));
-        p.M = T; p.Lout = p.Lin = T; p.stride = 1;
-        p.ldx = Tp; p.ldo = HID; p.N = 64; p.Ktot = Tp; p.ldw = Tp; p.w_rows = 64;
-        p.ngroups = B * HEADS; p.zdiv = HEADS;
-        p.x_zs0 = (long)HEADS * T * Tp; p.x_zs1 = (long)T * Tp;
-        p.w_zs0 = (long)HEADS * 64 * Tp; p.w_zs1 = (long)64 * Tp;
-        p.o_zs0 = (long)T * HID; p.o_zs1 = 64;
-        p.g[0].x = w.SC.f(); p.g[0].w = w.VT.f(); p.g[0].out = w.ATT.f();
-        p.g[0].nseg = 1; p.g[0].seg[0] = ConvSeg{0, 0, Tp, 1};
-        TS_TRY(run_conv(ctx, p, 0, s));
         TS_TRY(conv(E.outp, w.ATT.f(), HID, 1, (int)M, (int)M, 1, w.H.f(), HID, w.TMP.f(), HID, 0, HID, 0));
         TS_TRY(ln(w.TMP.f(), HID, E.ln1, nullptr, 0, w.H2.f()));
         TS_TRY(conv(E.ff1, w.H2.f(), HID, 1, (int)M, (int)M, 1, nullptr, 0, w.FF.f(), FFN, 0, FFN, 3));

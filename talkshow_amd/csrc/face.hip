@@ -5,8 +5,7 @@
 //   lerp_ln          linear_interpolation 50->30 fps (nets/spg/wav2vec.py:64-70) fused with the feature-projection
 //                    LayerNorm(512) (HF Wav2Vec2FeatureProjection; :107)
 //   layernorm_rows   nn.LayerNorm over channels (+ post-norm residual, ReLU): encoder LNs and nets/layers.py:142-151
-//   softmax_rows     softmax(QK^T * d^-0.5) of HF eager_attention_forward
-//   transpose_v      V^T per (clip, head) so that P.V is an NT GEMM
+//   attention        fused QK^T -> online soft-max -> PV of HF eager_attention_forward, one workgroup per 64 queries of a (clip, head)
 //   fill_id          id_mlp(one-hot id) broadcast over time and concatenated (nets/spg/s2g_face.py:127-130)
 #include "kernels.h"
 
@@ -183,83 +182,115 @@ hipError_t launch_lerp_ln(const float *x, int B, int Lin, int T, const float *ga
     return hipGetLastError();
 }
 
-// ---- softmax over the first S columns of each row (scaled), zero the padding columns ---------------------------
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ p, long rows, int S, int ld, float scale) {
-    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= rows) return;
-    const int lane = threadIdx.x & 63;
-    float *r = p + m * ld;
-    float v[8];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = c < S ? r[c] * scale : -INFINITY;
-        mx = fmaxf(mx, v[i]);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        v[i] = (lane + 64 * i) < S ? expf(v[i] - mx) : 0.f;
-        sum += v[i];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
-        if (c < ld) r[c] = v[i] * inv;
-    }
-}
-// rows longer than 512 (clips beyond ~17 s: the reference takes a wav of any length, smplx_face.py:169-218): the row is walked
-// three times (max, sum of exponentials, normalised write) instead of being held in registers; a lane visits its elements in
-// the same order and the lanes are combined in the same order as above, so a row of <= 512 would give the same bits
-__global__ __launch_bounds__(256) void softmax_rows_long_kernel(float *__restrict__ p, long rows, int S, int ld, float scale) {
-    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= rows) return;
-    const int lane = threadIdx.x & 63;
-    float *r = p + m * ld;
-    float mx = -INFINITY;
-    for (int c = lane; c < S; c += 64) mx = fmaxf(mx, r[c] * scale);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    float sum = 0.f;
-    for (int c = lane; c < S; c += 64) sum += expf(r[c] * scale - mx);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    const float inv = 1.0f / sum;
-    for (int c = lane; c < ld; c += 64) r[c] = c < S ? expf(r[c] * scale - mx) * inv : 0.f;
-}
-hipError_t launch_softmax_rows(float *p, long rows, int S, int ld, float scale, hipStream_t s) {
-    if (S > ld || S < 1) return hipErrorInvalidValue;
-    if (ld <= 512) hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p, rows, S, ld, scale);
-    else hipLaunchKernelGGL(softmax_rows_long_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p, rows, S, ld, scale);
-    return hipGetLastError();
-}
-
-// ---- V^T: vt[z][d][t] = qkv[b][t][v_col0 + h*64 + d], zero for t >= T ; z = b*heads + h ------------------------
-__global__ __launch_bounds__(256) void transpose_v_kernel(const float *__restrict__ qkv, int T, int ldq, int v_col0, int heads,
-                                                          float *__restrict__ vt, int Tp) {
-    __shared__ float tile[64][65];
+// ---- fused attention of one wav2vec2 encoder layer (HF eager_attention_forward: softmax(Q K^T * d^-0.5) V, wav2vec.py:76-143) ----
+// One workgroup = 64 queries of one (clip, head); wave w owns queries 16 w .. 16 w + 15 and walks the keys in tiles of 64 that all
+// four waves share through LDS (K as [key][d], V transposed to [d][key], rows pitched 68 floats: every ds_read_b128 of an operand
+// fragment is conflict-free).  Both products run on v_mfma_f32_16x16x4_f32 with the KEYS as the rows of the first product:
+//     S^T[key][query] = K Q^T        lane (li, lg) ends up with keys 4 lg .. 4 lg + 3 of each 16-key block for query li
+//     O^T[d][query]  += V^T P^T      ... which is exactly the B-operand fragment of the second product (k index = key 4 lg + e)
+// so the probabilities never leave their registers, a query's running max / sum are two xor-shuffles across the four lane groups,
+// and the (B, heads, T, T) score tensor of the launch-per-op form (QK^T GEMM -> softmax kernel -> V transpose kernel -> PV GEMM:
+// 0.77 GB written and read back per layer at batch 64) does not exist.  Online soft-max over the key tiles (running max m, sum l,
+// O rescaled by exp(m_old - m_new)): any T, no 2^31-entry score buffer.  fp32 throughout; the scale 2^-3 is exact.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int ATT_P = 68;
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float *__restrict__ qkv, int T, int HID, int heads, float scale,
+                                                           float *__restrict__ out) {
+    __shared__ float Ks[64 * ATT_P];
+    __shared__ float Vt[64 * ATT_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int z = blockIdx.y, b = z / heads, h = z - b * heads;
-    const int t0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int t = t0 + i;
-        tile[i][tx] = t < T ? qkv[((long)b * T + t) * ldq + v_col0 + h * 64 + tx] : 0.f;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const long ld = 3L * HID;
+    const float *base = qkv + (long)b * T * ld + h * 64;
+    // Q fragments, B operand of the first product: lane (li, lg) holds Q[q0 + li][16 qs + 4 lg + e]; rows past T are clamped (computed, never stored)
+    f32x4 qf[4];
+    {
+        const int qrow = q0 + li < T ? q0 + li : T - 1;
+#pragma unroll
+        for (int qs = 0; qs < 4; ++qs) qf[qs] = *reinterpret_cast<const f32x4 *>(base + (long)qrow * ld + 16 * qs + 4 * lg);
     }
-    __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
-        const int t = t0 + tx;
-        if (t < Tp) vt[((long)z * 64 + i) * Tp + t] = tile[tx][i];
+    f32x4 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < T; k0 += 64) {
+        __syncthreads();   // every wave is done reading the previous tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 4) + 16 * i, col = (tid & 15) * 4, key = k0 + row;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < T) {
+                kv = *reinterpret_cast<const f32x4 *>(base + (long)key * ld + HID + col);
+                vv = *reinterpret_cast<const f32x4 *>(base + (long)key * ld + 2 * HID + col);
+            }
+            *reinterpret_cast<f32x4 *>(&Ks[row * ATT_P + col]) = kv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Vt[(col + c) * ATT_P + row] = vv[c];
+        }
+        __syncthreads();
+        // S^T = K Q^T: 4 key blocks x (4 q-steps x 4) MFMAs
+        f32x4 sacc[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qs = 0; qs < 4; ++qs) {
+                const f32x4 kf = *reinterpret_cast<const f32x4 *>(&Ks[(kb * 16 + li) * ATT_P + 16 * qs + 4 * lg]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[qs][e], sacc[kb], 0, 0, 0);
+            }
+        }
+        // scale, mask the padding keys, online soft-max of query li (this lane's keys: k0 + 16 kb + 4 lg + r)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sv = (k0 + kb * 16 + 4 * lg + r) < T ? sacc[kb][r] * scale : -INFINITY;
+                sacc[kb][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx);          // finite: every tile holds at least one real key
+        const float alpha = expf(m - m_new);       // first tile: exp(-inf) = 0
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = expf(sacc[kb][r] - m_new);
+                sacc[kb][r] = pv;
+                rs += pv;
+            }
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        l = l * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] *= alpha;
+        // O^T += V^T P^T: 4 d blocks x 4 key blocks x 4 MFMAs; the B operand is the probability registers as they are
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const f32x4 vf = *reinterpret_cast<const f32x4 *>(&Vt[(db * 16 + li) * ATT_P + kb * 16 + 4 * lg]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], sacc[kb][e], o[db], 0, 0, 0);
+            }
+    }
+    if (q0 + li < T) {
+        const float inv = 1.0f / l;
+        float *dst = out + ((long)b * T + q0 + li) * HID + h * 64 + 4 * lg;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) *reinterpret_cast<f32x4 *>(dst + db * 16) = o[db] * inv;
     }
 }
-hipError_t launch_transpose_v(const float *qkv, int B, int T, int ldq, int v_col0, int heads, float *vt, int Tp,
-                              hipStream_t s) {
-    hipLaunchKernelGGL(transpose_v_kernel, dim3((Tp + 63) / 64, B * heads), dim3(256), 0, s, qkv, T, ldq, v_col0, heads, vt, Tp);
+// qkv (B, T, 3 HID) rows [q | k | v], heads of 64 channels -> out (B, T, HID) = concatenated heads' softmax(q k^T * scale) v
+hipError_t launch_attention(const float *qkv, int B, int T, int HID, int heads, float scale, float *out, hipStream_t s) {
+    if (HID != heads * 64 || B < 1 || T < 1 || (long)B * heads > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attention_kernel, dim3((T + 63) / 64, B * heads), dim3(256), 0, s, qkv, T, HID, heads, scale, out);
     return hipGetLastError();
 }
 

@@ -146,7 +146,7 @@ struct StateDict {
 };
 
 // ---- per-family device-time profiler (ts_prof_*) ------------------------------------------------------------
-enum { FAM_CONV = 0, FAM_SKINNY = 1, FAM_MISC = 2, FAM_COUNT = 3 };
+enum { FAM_CONV = 0, FAM_SKINNY = 1, FAM_MISC = 2, FAM_ATTN = 3, FAM_COUNT = 4 };
 
 struct Profiler {
     bool on = false;
@@ -158,9 +158,9 @@ struct Profiler {
     };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
-    double ms[FAM_COUNT] = {0, 0, 0};
-    double flops[FAM_COUNT] = {0, 0, 0};
-    long launches[FAM_COUNT] = {0, 0, 0};
+    double ms[FAM_COUNT] = {};
+    double flops[FAM_COUNT] = {};
+    long launches[FAM_COUNT] = {};
     hipEvent_t get_event();
     void begin(int fam, hipStream_t s);
     void end(hipStream_t s);
@@ -189,8 +189,11 @@ int run_skinny_batch(ts_ctx *ctx, const SkinnyParams *const *ps, int n, hipStrea
 struct MiscScope {
     ts_ctx *ctx;
     hipStream_t s;
-    MiscScope(ts_ctx *c, hipStream_t st) : ctx(c), s(st) {
-        if (ctx->prof.on) ctx->prof.begin(FAM_MISC, s);
+    MiscScope(ts_ctx *c, hipStream_t st, int fam = FAM_MISC, double flops = 0.0) : ctx(c), s(st) {
+        if (ctx->prof.on) {
+            ctx->prof.begin(fam, s);
+            ctx->prof.flops[fam] += flops;
+        }
     }
     ~MiscScope() {
         if (ctx->prof.on) ctx->prof.end(s);

@@ -235,8 +235,7 @@ hipError_t launch_layernorm_rows(const float *x, int ldx, long M, int C, const f
                                  const float *post_res, int ldr, int relu, float *out, int ldo, hipStream_t s);
 hipError_t launch_lerp_ln(const float *x, int B, int Lin, int T, const float *gamma, const float *beta, float *out,
                           hipStream_t s);
-hipError_t launch_softmax_rows(float *p, long rows, int S, int ld, float scale, hipStream_t s);
-hipError_t launch_transpose_v(const float *qkv, int B, int T, int ldq, int v_col0, int heads, float *vt, int Tp, hipStream_t s);
+hipError_t launch_attention(const float *qkv, int B, int T, int HID, int heads, float scale, float *out, hipStream_t s);
 hipError_t launch_fill_id(const float *id, int nc, const float *w, const float *bias, int nj, float *x, int ld, int col0,
                           int B, int T, hipStream_t s);
 

@@ -650,9 +650,13 @@ int ts_prof_enable(ts_ctx *ctx, int on) {
     return 0;
 }
 int ts_prof_read(ts_ctx *ctx, double *ms_out, int64_t *launches_out, double *flops_out, int reset) {
+    return ts_prof_read_n(ctx, 3, ms_out, launches_out, flops_out, reset);
+}
+int ts_prof_read_n(ts_ctx *ctx, int n_families, double *ms_out, int64_t *launches_out, double *flops_out, int reset) {
     if (!ctx) return fail("null ctx");
+    if (n_families < 1 || n_families > FAM_COUNT) return fail("ts_prof_read_n: 1..4 families");
     TS_TRY(ctx->prof.collect());
-    for (int i = 0; i < FAM_COUNT; ++i) {
+    for (int i = 0; i < n_families; ++i) {
         if (ms_out) ms_out[i] = ctx->prof.ms[i];
         if (launches_out) launches_out[i] = ctx->prof.launches[i];
         if (flops_out) flops_out[i] = ctx->prof.flops[i];
