@@ -279,13 +279,13 @@ def chain_roofline(w, lib, _lib, stream, mfcc, ids, H, pmc_key):
     # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), which cannot
     # run inside this process: the recorded value of the committed summary is quoted, with its source, never passed off as live
     traffic = traffic_source = None
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         pmc = os.path.join(REPO, "profiles", name)
         if os.path.exists(pmc):
             rec = json.load(open(pmc)).get(pmc_key, {})
             if rec.get("hbm_bytes_per_launch") is not None:
                 traffic = rec["hbm_bytes_per_launch"]
-                traffic_source = f"profiles/{name} [{pmc_key}] (rocprofv3 --pmc passes of tools/profile_r03.sh (r03) / tools/profile_r02.sh (r02), recorded at commit {rec.get('commit', 'see git log of the file')}; not measured by this run)"
+                traffic_source = f"profiles/{name} [{pmc_key}] (rocprofv3 --pmc passes of tools/profile_{name[:3]}.sh, recorded at commit {rec.get('commit', 'see git log of the file')}; not measured by this run)"
                 break
     return {"kernel": "skinny_gemm_f32 (PixelCNN per-position GEMM chain)", "clips_per_stage": M, "bound": "mfma",
             "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
@@ -326,16 +326,19 @@ def whole_body_block(w, _lib, local, batch_body):
     wav = torch.from_numpy(synth.wav16(5000, n, 160000)).to(dev)
     fid = torch.nn.functional.one_hot(torch.arange(n) % 4, 4).float().to(dev)
 
-    def step():
+    def step(overlap=True):
         return parallel.whole_body_local(w, face, mfcc, ids, wav, fid, mode=_lib.TS_SAMPLE_GREEDY, clip_index0=0,
-                                         batch_body=batch_body, batch_face=64)
+                                         batch_body=batch_body, batch_face=64, overlap=overlap)
     rows = step()
+    rows_serial = step(overlap=False)
     torch.cuda.synchronize()
-    assert tuple(rows.shape) == (n, T, 265) and bool(torch.isfinite(rows).all())
+    assert tuple(rows.shape) == (n, T, 265) and bool(torch.isfinite(rows).all()) and torch.equal(rows, rows_serial)
     t32 = timed(step)
+    t32_serial = timed(lambda: step(overlap=False))
     out = {"workload": f"BASELINE configs[4] at one rank: {n} synthetic 10 s clips per step, body_pixel greedy (one pass of {min(n, batch_body)} "
                        "clips) + face generator (batches of 64) -> (128, 300, 265) rows; no exchange at N = 1",
-           "fp32": {"ms_per_step": t32 * 1e3, "frames_per_s": n * T / t32}}
+           "fp32": {"ms_per_step": t32 * 1e3, "frames_per_s": n * T / t32,
+                    "one_stream_ms_per_step": t32_serial * 1e3, "what": "body path on a side stream under the face generator's GEMMs (bit-identical rows)"}}
     try:
         face.generator.set_arith(3)
         rows3 = step()

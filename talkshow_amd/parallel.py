@@ -81,8 +81,20 @@ def _empty_like_output(generate_fn, mfcc, ids):
     return probe
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    """one library-created side stream per device (its own hardware queue and scratch arena)"""
+    from . import _lib
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _side_streams:
+        _side_streams[idx] = _lib.create_streams(1, idx)[0]
+    return _side_streams[idx]
+
+
 def whole_body_local(body, face, mfcc, ids, wav, face_ids, mode=None, seed=0, clip_index0=0, batch_body=32, batch_face=64,
-                     stand=False):
+                     stand=False, overlap=True):
     """Whole-body generation of THIS rank's clips (no collective): body path in batches of `batch_body`, face path in
     batches of `batch_face`, (n, Tf, 265) rows assembled on the GPU (`pose_index.assemble_full` = demo.py:207-229 +
     part2full).  mfcc (n,T,64), ids (n,), wav (n,S) 16 kHz samples, face_ids (n,4); `clip_index0` = global index of
@@ -95,12 +107,23 @@ def whole_body_local(body, face, mfcc, ids, wav, face_ids, mode=None, seed=0, cl
     if n == 0:
         return torch.zeros((0, frames, 265), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
     poses, faces = [], []
-    for s in range(0, n, batch_body):
-        e = min(s + batch_body, n)
-        poses.append(body.generate_batch(mfcc[s:e], ids[s:e], mode=mode, seed=seed, clip_index0=clip_index0 + s)[1])
+    # the two generators are independent until the assembly: the body path (its autoregressive chain is latency-bound and leaves most
+    # of the matrix pipe idle) goes to a side stream and runs under the face generator's GEMMs; both join before the assembly
+    cur = torch.cuda.current_stream()
+    side = _side_stream(cur.device) if overlap else cur
+    if overlap:
+        side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        for s in range(0, n, batch_body):
+            e = min(s + batch_body, n)
+            poses.append(body.generate_batch(mfcc[s:e], ids[s:e], mode=mode, seed=seed, clip_index0=clip_index0 + s)[1])
     for s in range(0, n, batch_face):
         e = min(s + batch_face, n)
         faces.append(face.generator.run(wav[s:e], face_ids[s:e], frames))
+    if overlap:
+        cur.wait_stream(side)
+        for t in poses:
+            t.record_stream(cur)
     return assemble_full(torch.cat(poses, 0), torch.cat(faces, 0), stand=stand)
 
 
