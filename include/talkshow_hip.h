@@ -123,6 +123,23 @@ int ts_pixelcnn_generate(ts_pixelcnn *pix, const int64_t *label_dev, const float
                          float *logits_dev, const int64_t *pre_codes_dev, const float *pre_aud_dev, int H0,
                          void *stream);
 
+/* GatedPixelCNN(input_dim, dim, n_layers, n_classes, audio, bh_model=False) — the single-stack form (gated_pixelcnn_v2.py:37-42,
+ * 80-85,147-150): vertical kernels one column wide, out_v = horiz_resid(gate(vert_stack(x_v) + class)) [+ x_v], logits from x_v; the
+ * grid's W columns never mix, so the W codes of a row are drawn together.  Same state_dict keys as the reference module (the
+ * vert_to_horiz / horiz_stack / fusion_h tensors it also holds are not read).  audio != 0: embedding_aud + fusion_v in front of
+ * layer 1.  Not used by config/body_pixel.json; eager launches, no tuning. */
+typedef struct ts_pixelcnn_v ts_pixelcnn_v;
+int ts_pixelcnn_v_create(ts_ctx *ctx, const ts_tensor *sd, int n, int input_dim, int dim, int n_layers, int n_classes, int audio,
+                         int aud_dim, ts_pixelcnn_v **out);
+void ts_pixelcnn_v_destroy(ts_pixelcnn_v *pix);
+/* generate / forward of that form: label_dev (B,), aud_dev (B,H,aud_dim) or NULL (audio == 0), grid (H, W) with W a power of two;
+ * codes_dev (B,H,W) int64 out (in for TS_TEACHER_FORCED), logits_dev optional (B,H,W,input_dim), uniforms_dev (B,H,W) for
+ * TS_SAMPLE_UNIFORMS; Philox position of (row, column) = (H0 + row) * W + column; prefix as in ts_pixelcnn_generate
+ * (pre_codes_dev (B,H0,W), pre_aud_dev (B,H0,aud_dim)). */
+int ts_pixelcnn_v_generate(ts_pixelcnn_v *pix, const int64_t *label_dev, const float *aud_dev, int B, int H, int W, int mode,
+                           const float *uniforms_dev, uint64_t seed, int64_t clip_index0, int64_t *codes_dev, float *logits_dev,
+                           const int64_t *pre_codes_dev, const float *pre_aud_dev, int H0, void *stream);
+
 /* Launch count and algorithmic flops (2*M*N*K over every skinny_gemm launch) of the hipGraph captured for
  * (B, H, mode) on `stream` — what one replay executes; used by bench.py for the roofline line. */
 int ts_pixelcnn_graph_stats(ts_pixelcnn *pix, void *stream, int B, int H, int mode, int64_t *launches, double *flops);

@@ -220,12 +220,18 @@ def causal_weights(sd, n_layers):
     return sd
 
 
-def gated_masked_conv2d(x_v, x_h, label, sd, p, kernel, residual):
-    """GatedMaskedConv2d.forward, bh_model=True (`gated_pixelcnn_v2.py:61-87`)."""
+def gated_masked_conv2d(x_v, x_h, label, sd, p, kernel, residual, bh_model=True):
+    """GatedMaskedConv2d.forward (`gated_pixelcnn_v2.py:61-87`); bh_model=False: the `else` branch (:80-85), vertical kernels one
+    column wide (:37-38), out_h = out_v."""
     h = sd[p + ".class_cond_embedding.weight"][label]                       # (B, 2*dim)
-    h_vert = conv2d(x_v, sd[p + ".vert_stack.weight"], sd[p + ".vert_stack.bias"], kernel // 2, 1)
+    h_vert = conv2d(x_v, sd[p + ".vert_stack.weight"], sd[p + ".vert_stack.bias"], kernel // 2, 1 if bh_model else 0)
     h_vert = h_vert[:, :, :x_v.shape[-2], :]
     out_v = gated_activation(h_vert + h[:, :, None, None])
+    if not bh_model:
+        out_v = conv2d(out_v, sd[p + ".horiz_resid.weight"], sd[p + ".horiz_resid.bias"], 0, 0)
+        if residual:
+            out_v = out_v + x_v
+        return out_v, out_v
     h_horiz = conv2d(x_h, sd[p + ".horiz_stack.weight"], sd[p + ".horiz_stack.bias"], 0, 1)
     h_horiz = h_horiz[:, :, :, :x_h.shape[-1]]
     v2h = conv2d(h_vert, sd[p + ".vert_to_horiz.weight"], sd[p + ".vert_to_horiz.bias"], 0, 0)
@@ -236,21 +242,23 @@ def gated_masked_conv2d(x_v, x_h, label, sd, p, kernel, residual):
     return out_v, out_h
 
 
-def pixelcnn_forward(x, label, aud, sd, n_layers):
-    """GatedPixelCNN.forward (`gated_pixelcnn_v2.py:130-150`), audio=True, bh_model=True, eval mode.
+def pixelcnn_forward(x, label, aud, sd, n_layers, audio=True, bh_model=True):
+    """GatedPixelCNN.forward (`gated_pixelcnn_v2.py:130-150`), eval mode; audio / bh_model as the constructor's flags (the shipped
+    configuration is audio=True, bh_model=True).
 
-    x (B,H,2) int64 codes, label (B,) int64, aud (B,256,H,2) -> logits (B,input_dim,H,2).
+    x (B,H,W) int64 codes, label (B,) int64, aud (B,256,H,W) or None -> logits (B,input_dim,H,W).
     `sd` must already have gone through `causal_weights`.
     """
     e = sd["embedding.weight"][x]                                           # (B,H,W,C)
     xv = xh = np.ascontiguousarray(e.transpose(0, 3, 1, 2))
     for i in range(n_layers):
-        if i == 1:
+        if i == 1 and audio:
             a = conv2d(aud, sd["embedding_aud.weight"], sd["embedding_aud.bias"], 0, 0)
             xv = conv2d(np.concatenate([xv, a], 1), sd["fusion_v.weight"], sd["fusion_v.bias"], 0, 0)
-            xh = conv2d(np.concatenate([xh, a], 1), sd["fusion_h.weight"], sd["fusion_h.bias"], 0, 0)
-        xv, xh = gated_masked_conv2d(xv, xh, label, sd, f"layers.{i}", 7 if i == 0 else 3, i != 0)
-    y = relu(conv2d(xh, sd["output_conv.0.weight"], sd["output_conv.0.bias"], 0, 0))
+            if bh_model:
+                xh = conv2d(np.concatenate([xh, a], 1), sd["fusion_h.weight"], sd["fusion_h.bias"], 0, 0)
+        xv, xh = gated_masked_conv2d(xv, xh, label, sd, f"layers.{i}", 7 if i == 0 else 3, i != 0, bh_model)
+    y = relu(conv2d(xh if bh_model else xv, sd["output_conv.0.weight"], sd["output_conv.0.bias"], 0, 0))
     return conv2d(y, sd["output_conv.2.weight"], sd["output_conv.2.bias"], 0, 0)
 
 
@@ -260,7 +268,8 @@ def softmax(x):
     return (e / e.sum(axis=-1, keepdims=True)).astype(F32)
 
 
-def pixelcnn_generate(label, aud, sd, n_layers, H, uniforms=None, return_logits=False, pre_latents=None, pre_audio=None):
+def pixelcnn_generate(label, aud, sd, n_layers, H, uniforms=None, return_logits=False, pre_latents=None, pre_audio=None,
+                      audio=True, bh_model=True, W=2):
     """GatedPixelCNN.generate (`gated_pixelcnn_v2.py:152-177`) — the O(H^2) full-grid recompute, as written.
 
     `uniforms is None`: greedy harness of SURVEY.md §0.3 (argmax of logits[:, :, i, j], ties -> lowest
@@ -271,17 +280,18 @@ def pixelcnn_generate(label, aud, sd, n_layers, H, uniforms=None, return_logits=
     audio rows are prepended, positions h0..h0+H-1 are generated, and only those are returned.
     """
     sd = causal_weights(sd, n_layers)
-    B = aud.shape[0]
-    x = np.zeros((B, H, 2), np.int64)
+    B = len(label)
+    x = np.zeros((B, H, W), np.int64)
     h0 = 0
     if pre_latents is not None:
         x = np.concatenate([np.asarray(pre_latents, np.int64), x], axis=1)
-        aud = np.concatenate([pre_audio, aud], axis=2)
+        if audio:
+            aud = np.concatenate([pre_audio, aud], axis=2)
         h0 = pre_latents.shape[1]
     logs = []
     for i in range(h0, h0 + H):
-        for j in range(2):
-            lg = pixelcnn_forward(x, label, aud, sd, n_layers)[:, :, i, j]
+        for j in range(W):
+            lg = pixelcnn_forward(x, label, aud, sd, n_layers, audio, bh_model)[:, :, i, j]
             if return_logits:
                 logs.append(lg.copy())
             if uniforms is None:
@@ -290,7 +300,7 @@ def pixelcnn_generate(label, aud, sd, n_layers, H, uniforms=None, return_logits=
                 x[:, i, j] = sample_inverse_cdf(lg, uniforms[:, i - h0, j])
     x = x[:, h0:]
     if return_logits:
-        return x, np.stack(logs, 1).reshape(B, H, 2, -1)
+        return x, np.stack(logs, 1).reshape(B, H, W, -1)
     return x
 
 

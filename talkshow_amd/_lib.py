@@ -49,6 +49,9 @@ SIGNATURES = {
     "ts_pixelcnn_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ts_pixelcnn_destroy": (None, [_vp]),
     "ts_pixelcnn_generate": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ts_pixelcnn_v_create": (_i, [_vp, C.POINTER(TsTensor), _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ts_pixelcnn_v_destroy": (None, [_vp]),
+    "ts_pixelcnn_v_generate": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _u64, _i64, _vp, _vp, _vp, _vp, _i, _vp]),
     "ts_pixelcnn_stream_open": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "ts_pixelcnn_stream_step": (_i, [_vp, _vp, _i, _i, _vp, _u64, _i64, _vp, _vp]),
     "ts_pixelcnn_stream_rows": (_i64, [_vp]),

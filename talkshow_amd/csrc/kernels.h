@@ -207,7 +207,8 @@ __device__ inline float det_expf(float x) {
 }
 
 struct SampleParams {
-    const float *logits;   // [B][V]
+    const float *logits;   // row b at logits + b * (logit_stride ? logit_stride : V)
+    long logit_stride;     // 0 = V (contiguous rows)
     int B, V;
     int mode;              // TS_SAMPLE_* ; TEACHER_FORCED copies
     const float *uniforms; // element for clip b at uniforms[b * u_stride]

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleParams p) {
     __shared__ int si[256];
     __shared__ float s_thr;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *lg = p.logits + (long)b * p.V;
+    const float *lg = p.logits + (long)b * (p.logit_stride ? p.logit_stride : (long)p.V);
 
     // Every thread owns `chunk` consecutive logits [v0, v1).  For the production vocabulary (V = 2048: chunk = 8) they are
     // fetched up front with two 16-byte loads — this kernel sits on the dependent chain, and a load-per-iteration loop

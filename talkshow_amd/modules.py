@@ -297,13 +297,18 @@ class AE(VQVAE):
 
 
 class GatedPixelCNN(NativeModule):
-    """`gated_pixelcnn_v2.GatedPixelCNN(input_dim, dim, n_layers, n_classes, audio=True, bh_model=True)`."""
+    """`gated_pixelcnn_v2.GatedPixelCNN(input_dim, dim, n_layers, n_classes, audio, bh_model)`.
+
+    audio=True, bh_model=True (config/body_pixel.json) is the tuned incremental chain (`ts_pixelcnn_*`).  The other three
+    constructor variants are supported as the reference supports them, untuned: audio=False with bh_model=True runs the same
+    chain with an identity fusion and zero audio rows (bit-identical to having no fusion: 1.0 * x + 0 is exact); bh_model=False
+    is the single vertical stack (`ts_pixelcnn_v_*`: columns never mix, grid width any power of two)."""
 
     def __init__(self, input_dim=256, dim=64, n_layers=15, n_classes=10, audio=False, bh_model=False, aud_dim=256):
-        if not (audio and bh_model):
-            raise NotImplementedError("only the audio=True, bh_model=True configuration of config/body_pixel.json is built")
         self.input_dim, self.dim, self.n_layers, self.n_classes, self.aud_dim = input_dim, dim, n_layers, n_classes, aud_dim
-        super().__init__(synth.pixelcnn_state_dict(0, input_dim, dim, n_layers, n_classes, aud_dim))
+        self.audio, self.bh_model = bool(audio), bool(bh_model)
+        super().__init__(synth.pixelcnn_state_dict(0, input_dim, dim, n_layers, n_classes, aud_dim, audio=self.audio,
+                                                   bh_model=self.bh_model))
 
     def _after_load(self):
         # the reference zeroes these taps in place on every forward of layer 0 (make_causal, gated_pixelcnn_v2.py:57-63),
@@ -312,21 +317,48 @@ class GatedPixelCNN(NativeModule):
         self._sd["layers.0.horiz_stack.weight"][:, :, :, -1] = 0
 
     def _create(self, ctx):
-        arr, n, keep = _lib.pack_state_dict(self._sd)
         h = C.c_void_p()
+        if not self.bh_model:
+            arr, n, keep = _lib.pack_state_dict(self._sd)
+            _lib.check(_lib.load().ts_pixelcnn_v_create(ctx, arr, n, self.input_dim, self.dim, self.n_layers, self.n_classes,
+                                                        int(self.audio), self.aud_dim, C.byref(h)))
+            return h
+        sd = self._sd
+        if not self.audio:   # no audio branch: an identity fusion over zero audio rows is the same arithmetic, exactly
+            D = self.dim
+            eye = torch.cat([torch.eye(D), torch.zeros(D, D)], 1).reshape(D, 2 * D, 1, 1)
+            sd = OrderedDict(sd)
+            sd["embedding_aud.weight"], sd["embedding_aud.bias"] = torch.zeros(D, self.aud_dim, 1, 1), torch.zeros(D)
+            sd["fusion_v.weight"], sd["fusion_v.bias"] = eye.clone(), torch.zeros(D)
+            sd["fusion_h.weight"], sd["fusion_h.bias"] = eye.clone(), torch.zeros(D)
+        arr, n, keep = _lib.pack_state_dict(sd)
         _lib.check(_lib.load().ts_pixelcnn_create(ctx, arr, n, self.input_dim, self.dim, self.n_layers, self.n_classes,
                                                   self.aud_dim, C.byref(h)))
         return h
 
     def _destroy(self, h):
-        _lib.load().ts_pixelcnn_destroy(h)
+        (_lib.load().ts_pixelcnn_destroy if self.bh_model else _lib.load().ts_pixelcnn_v_destroy)(h)
 
     def run(self, label, aud_rows, mode=_lib.TS_SAMPLE_PHILOX, codes=None, uniforms=None, seed=0, clip_index0=0,
-            want_logits=False, pre_codes=None, pre_aud=None):
-        """aud_rows (B,H,aud_dim) device; returns (codes (B,H,2) int64, logits (B,H,2,V) or None)."""
+            want_logits=False, pre_codes=None, pre_aud=None, shape=None):
+        """aud_rows (B,H,aud_dim) device (None for audio=False: pass shape=(B,H)); returns (codes (B,H,W) int64, logits
+        (B,H,W,V) or None); W = 2 unless bh_model=False and shape=(B,H,W) says otherwise."""
         dev = self._dev()
-        aud_rows = _dev_f32(aud_rows, dev)
-        B, H, _ = aud_rows.shape
+        W = 2
+        if aud_rows is not None:
+            aud_rows = _dev_f32(aud_rows, dev)
+            B, H, _ = aud_rows.shape
+            if shape is not None and len(shape) == 3:
+                W = int(shape[2])
+        else:
+            if self.audio:
+                raise ValueError("this network was built with audio=True: aud_rows is required")
+            B, H = int(shape[0]), int(shape[1])
+            W = int(shape[2]) if len(shape) == 3 else 2
+        if self.bh_model and W != 2:
+            raise NotImplementedError("bh_model grids have exactly 2 columns (body, hand)")
+        if self.bh_model and aud_rows is None:
+            aud_rows = torch.zeros((B, H, self.aud_dim), dtype=torch.float32, device=dev)
         label = _index_tensor(label, self.n_classes, "class label", dev)
         if label.numel() == 1 and B > 1:
             label = label.repeat(B)
@@ -335,15 +367,23 @@ class GatedPixelCNN(NativeModule):
         if mode == _lib.TS_TEACHER_FORCED:
             codes = torch.as_tensor(codes, dtype=torch.int64, device=dev).contiguous()
         else:
-            codes = torch.zeros((B, H, 2), dtype=torch.int64, device=dev)
-        logits = torch.empty((B, H, 2, self.input_dim), dtype=torch.float32, device=dev) if want_logits else None
+            codes = torch.zeros((B, H, W), dtype=torch.int64, device=dev)
+        logits = torch.empty((B, H, W, self.input_dim), dtype=torch.float32, device=dev) if want_logits else None
         if uniforms is not None:
             uniforms = _dev_f32(uniforms, dev)
         H0 = 0
         if pre_codes is not None:
             pre_codes = torch.as_tensor(pre_codes, dtype=torch.int64, device=dev).contiguous()
-            pre_aud = _dev_f32(pre_aud, dev)
             H0 = pre_codes.shape[1]
+            if pre_aud is not None:
+                pre_aud = _dev_f32(pre_aud, dev)
+            elif self.bh_model:
+                pre_aud = torch.zeros((B, H0, self.aud_dim), dtype=torch.float32, device=dev)
+        if not self.bh_model:
+            _lib.check(_lib.load().ts_pixelcnn_v_generate(
+                self.handle(), _lib.dptr(label), _lib.dptr(aud_rows), B, H, W, mode, _lib.dptr(uniforms), int(seed) & (2 ** 64 - 1),
+                int(clip_index0), _lib.dptr(codes), _lib.dptr(logits), _lib.dptr(pre_codes), _lib.dptr(pre_aud), H0, _lib.stream_ptr()))
+            return codes, logits
         _lib.check(_lib.load().ts_pixelcnn_generate(
             self.handle(), _lib.dptr(label), _lib.dptr(aud_rows), B, H, mode, _lib.dptr(uniforms), int(seed) & (2 ** 64 - 1),
             int(clip_index0), _lib.dptr(codes), _lib.dptr(logits), _lib.dptr(pre_codes), _lib.dptr(pre_aud), H0,
@@ -353,6 +393,8 @@ class GatedPixelCNN(NativeModule):
     def open_stream(self, label, batch_size, max_chunk_rows):
         """A generation session with a persistent row cache (`ts_pixelcnn_stream_*`): `.step(aud_rows)` continues the
         clip(s) where the previous step stopped, at a cost independent of the history length."""
+        if not (self.audio and self.bh_model):
+            raise NotImplementedError("streaming sessions exist for the shipped configuration (audio=True, bh_model=True)")
         return PixelCNNStream(self, label, batch_size, max_chunk_rows)
 
     # --- reference call shapes ---
@@ -363,21 +405,20 @@ class GatedPixelCNN(NativeModule):
         Default is stochastic like the reference (softmax + one multinomial draw per position), with Philox uniforms
         seeded from torch's default generator; `mode=TS_SAMPLE_GREEDY` gives the argmax harness.
         """
-        if shape[1] != 2:
-            raise NotImplementedError("bh_model grids have exactly 2 columns (body, hand)")
-        rows = aud_feat[..., 0].transpose(1, 2)             # the 2 columns are copies (smplx_body_pixel.py:274)
+        rows = aud_feat[..., 0].transpose(1, 2) if aud_feat is not None else None      # the columns are copies (smplx_body_pixel.py:274)
         pre_rows = pre_audio[..., 0].transpose(1, 2) if pre_audio is not None else None
         if mode is None:
             mode = _lib.TS_SAMPLE_PHILOX if uniforms is None else _lib.TS_SAMPLE_UNIFORMS
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if mode == _lib.TS_SAMPLE_PHILOX else 0
-        codes, _ = self.run(label, rows, mode=mode, uniforms=uniforms, seed=seed, pre_codes=pre_latents, pre_aud=pre_rows)
+        codes, _ = self.run(label, rows, mode=mode, uniforms=uniforms, seed=seed, pre_codes=pre_latents, pre_aud=pre_rows,
+                            shape=(batch_size, shape[0], shape[1]))
         return codes
 
     def __call__(self, x, label, aud=None):
         """`GatedPixelCNN.forward` (`gated_pixelcnn_v2.py:130-150`): x (B,H,2) codes -> logits (B,input_dim,H,2)."""
-        rows = aud[..., 0].transpose(1, 2)
-        _, logits = self.run(label, rows, mode=_lib.TS_TEACHER_FORCED, codes=x, want_logits=True)
+        rows = aud[..., 0].transpose(1, 2) if aud is not None else None
+        _, logits = self.run(label, rows, mode=_lib.TS_TEACHER_FORCED, codes=x, want_logits=True, shape=tuple(x.shape))
         return logits.permute(0, 3, 1, 2)
 
 

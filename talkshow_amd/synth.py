@@ -144,8 +144,10 @@ def ae_state_dict(seed=0, in_dim=129, embedding_dim=64, num_hiddens=1024, num_re
     return sd
 
 
-def pixelcnn_state_dict(seed=0, input_dim=2048, dim=256, n_layers=15, n_classes=4, aud_dim=256):
-    """`GatedPixelCNN(input_dim, dim, n_layers, n_classes, audio=True, bh_model=True)` (`gated_pixelcnn_v2.py:90-128`)."""
+def pixelcnn_state_dict(seed=0, input_dim=2048, dim=256, n_layers=15, n_classes=4, aud_dim=256, audio=True, bh_model=True):
+    """`GatedPixelCNN(input_dim, dim, n_layers, n_classes, audio, bh_model)` (`gated_pixelcnn_v2.py:90-128`); the shipped
+    configuration is audio=True, bh_model=True.  audio=False drops the three audio tensors; bh_model=False makes the vertical
+    kernels one column wide (`:37-38`; the module still holds vert_to_horiz / horiz_stack / fusion_h, which its forward never reads)."""
     b = _Builder(seed, 303)
 
     def conv2d(prefix, cout, cin, kh, kw, gain, valid=None):
@@ -153,15 +155,17 @@ def pixelcnn_state_dict(seed=0, input_dim=2048, dim=256, n_layers=15, n_classes=
         b.normal(prefix + ".weight", (cout, cin, kh, kw), gain / np.sqrt(fan_in))
         b.normal(prefix + ".bias", (cout,), 0.1)
 
-    conv2d("embedding_aud", dim, aud_dim, 1, 1, 1.0)
-    conv2d("fusion_v", dim, 2 * dim, 1, 1, 1.0)
-    conv2d("fusion_h", dim, 2 * dim, 1, 1, 1.0)
+    if audio:
+        conv2d("embedding_aud", dim, aud_dim, 1, 1, 1.0)
+        conv2d("fusion_v", dim, 2 * dim, 1, 1, 1.0)
+        conv2d("fusion_h", dim, 2 * dim, 1, 1, 1.0)
     b.normal("embedding.weight", (input_dim, dim), 1.0)
+    kw = 3 if bh_model else 1
     for i in range(n_layers):
         kh = 4 if i == 0 else 2
         p = f"layers.{i}"
         b.normal(p + ".class_cond_embedding.weight", (n_classes, 2 * dim), 0.3)
-        conv2d(p + ".vert_stack", 2 * dim, dim, kh, 3, 1.6, valid=(kh - 1 if i == 0 else kh) * 2)
+        conv2d(p + ".vert_stack", 2 * dim, dim, kh, kw, 1.6, valid=(kh - 1 if i == 0 else kh) * (2 if bh_model else 1))
         conv2d(p + ".vert_to_horiz", 2 * dim, 2 * dim, 1, 1, 0.7)
         conv2d(p + ".horiz_stack", 2 * dim, dim, 1, 2, 1.6, valid=1 if i == 0 else 2)
         conv2d(p + ".horiz_resid", dim, dim, 1, 1, 1.5)

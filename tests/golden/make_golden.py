@@ -177,6 +177,35 @@ def main():
              full_logits=full_logits.permute(0, 2, 3, 1).numpy(), margin=m,
              cfg=np.asarray([kw["input_dim"], kw["dim"], kw["n_layers"], 4, 7]))
 
+    # ---- 3b. the other constructor variants of GatedPixelCNN (`gated_pixelcnn_v2.py:90-128`): audio=False and / or bh_model=False
+    # (single vertical stack, columns never mix; grid widths 2 and 4).  No shipped config uses them; same greedy harness.
+    if want("pix_variants"):
+        out = {}
+        for tag, audio, bh, Wd in (("noaud_bh", False, True, 2), ("aud_v", True, False, 2), ("noaud_v", False, False, 4)):
+            kw = dict(input_dim=128, dim=64, n_layers=4)
+            sd = synth.pixelcnn_state_dict(seed=11, audio=audio, bh_model=bh, **kw)
+            pix = quiet(GatedPixelCNN, kw["input_dim"], kw["dim"], kw["n_layers"], 4, audio, bh)
+            pix.load_state_dict(T(sd), strict=True)                       # pins the variant's key set / shapes
+            pix.eval()
+            B, H = 3, 8
+            rng = np.random.default_rng(17)
+            aud = rng.standard_normal((B, H, 256)).astype(np.float32)
+            label = synth.speaker_ids(B)
+            aud_t = torch.from_numpy(aud).permute(0, 2, 1).unsqueeze(-1).repeat(1, 1, 1, Wd) if audio else None
+            x = torch.zeros((B, H, Wd), dtype=torch.int64)
+            step_logits = torch.zeros((B, H, Wd, kw["input_dim"]))
+            with torch.no_grad():
+                for i in range(H):
+                    for j in range(Wd):
+                        lg = pix(x, torch.from_numpy(label), aud_t) if audio else pix(x, torch.from_numpy(label))
+                        step_logits[:, i, j] = lg[:, :, i, j]
+                        x[:, i, j] = torch.argmax(lg[:, :, i, j], dim=-1)
+                full = pix(x, torch.from_numpy(label), aud_t) if audio else pix(x, torch.from_numpy(label))
+            m = margins(step_logits.numpy())
+            print("pix_variants", tag, "margin min/median", float(m.min()), float(np.median(m)), "uniq", x.unique().numel())
+            out.update({f"{tag}_codes": x.numpy(), f"{tag}_step_logits": step_logits.numpy(), f"{tag}_full_logits": full.permute(0, 2, 3, 1).numpy()})
+        save("pix_variants", aud=aud, label=label, cfg=np.asarray([128, 64, 4, 4, 11]), **out)
+
     # ---- 4. end-to-end through the reference WRAPPERS (ckpt plumbing included) --------------------
     if want("body_e2e_full") or want("body_vq_e2e_full"):
         tmp = tempfile.mkdtemp(prefix="ts_golden_")

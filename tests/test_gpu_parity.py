@@ -296,6 +296,52 @@ def test_pixelcnn_golden(hip, golden, name):
     np.testing.assert_array_equal(full.permute(0, 2, 3, 1).cpu().numpy(), logits.cpu().numpy())
 
 
+@pytest.mark.parametrize("tag,audio,bh", [("noaud_bh", False, True), ("aud_v", True, False), ("noaud_v", False, False)])
+def test_pixelcnn_constructor_variants(hip, golden, tag, audio, bh):
+    """GatedPixelCNN(audio=False and / or bh_model=False) (`gated_pixelcnn_v2.py:37-42,80-85,137-150`) against the reference's own
+    module: teacher-forced logits of every position, free-running greedy codes bit-exact, the reference call shapes of forward /
+    generate, injected-uniform sampling against the oracle, and the continuity prefix.  bh_model=False is `ts_pixelcnn_v_*` (single
+    vertical stack; the 4-column grid of the third case draws a row's four codes together)."""
+    from talkshow_amd import _lib
+    from talkshow_amd.modules import GatedPixelCNN
+    g = golden("pix_variants")
+    input_dim, dim, n_layers, n_cls, seed = [int(v) for v in g["cfg"]]
+    sd = synth.pixelcnn_state_dict(seed=seed, input_dim=input_dim, dim=dim, n_layers=n_layers, n_classes=n_cls, audio=audio, bh_model=bh)
+    m = GatedPixelCNN(input_dim, dim, n_layers, n_cls, audio, bh).cuda()
+    m.load_state_dict(synth.to_torch(sd))
+    ref = g[tag + "_codes"]
+    B, H, W = ref.shape
+    aud = g["aud"] if audio else None
+    _, logits = m.run(g["label"], aud, mode=_lib.TS_TEACHER_FORCED, codes=ref, want_logits=True, shape=(B, H, W))
+    np.testing.assert_allclose(logits.cpu().numpy(), g[tag + "_full_logits"], atol=3e-4, rtol=0)
+    codes, step = m.run(g["label"], aud, mode=_lib.TS_SAMPLE_GREEDY, want_logits=True, shape=(B, H, W))
+    np.testing.assert_allclose(step.cpu().numpy(), g[tag + "_step_logits"], atol=3e-4, rtol=0)
+    np.testing.assert_array_equal(codes.cpu().numpy(), ref)
+    # reference call shapes: forward(x, label[, aud (B,256,H,W)]) -> (B,V,H,W); generate(label, shape, batch_size[, aud_feat])
+    aud4 = torch.from_numpy(g["aud"]).cuda().transpose(1, 2).unsqueeze(-1).repeat(1, 1, 1, W) if audio else None
+    full = m(torch.from_numpy(ref).cuda(), torch.from_numpy(g["label"]).cuda(), aud4) if audio else m(torch.from_numpy(ref).cuda(), torch.from_numpy(g["label"]).cuda())
+    np.testing.assert_array_equal(full.permute(0, 2, 3, 1).cpu().numpy(), logits.cpu().numpy())
+    gen = m.generate(torch.from_numpy(g["label"]).cuda(), shape=(H, W), batch_size=B, aud_feat=aud4, mode=_lib.TS_SAMPLE_GREEDY)
+    np.testing.assert_array_equal(gen.cpu().numpy(), ref)
+    # stochastic decode on injected uniforms == the oracle's inverse-CDF generate; device Philox == oracle Philox (position r * W + j)
+    u = np.zeros((B, H, W), np.float32)
+    for b in range(B):
+        for r in range(H):
+            for j in range(W):
+                u[b, r, j] = O.philox_uniform(77, 5 + b, r * W + j)
+    aud_o = np.repeat(g["aud"].transpose(0, 2, 1)[:, :, :, None], W, axis=3) if audio else None
+    want = O.pixelcnn_generate(g["label"], aud_o, sd, n_layers, H, uniforms=u, audio=audio, bh_model=bh, W=W)
+    got_u, _ = m.run(g["label"], aud, mode=_lib.TS_SAMPLE_UNIFORMS, uniforms=u, shape=(B, H, W))
+    got_p, _ = m.run(g["label"], aud, mode=_lib.TS_SAMPLE_PHILOX, seed=77, clip_index0=5, shape=(B, H, W))
+    np.testing.assert_array_equal(got_u.cpu().numpy(), want)
+    np.testing.assert_array_equal(got_p.cpu().numpy(), want)
+    # continuity prefix: the greedy tail behind the greedy head == the single greedy run
+    H0 = 3
+    tail, _ = m.run(g["label"], g["aud"][:, H0:] if audio else None, mode=_lib.TS_SAMPLE_GREEDY, pre_codes=ref[:, :H0],
+                    pre_aud=g["aud"][:, :H0] if audio else None, shape=(B, H - H0, W))
+    np.testing.assert_array_equal(tail.cpu().numpy(), ref[:, H0:])
+
+
 def test_pixelcnn_sampling_and_prefix(hip, golden):
     """Stochastic decode with injected uniforms == oracle's inverse-CDF generate; continuity prefix reproduces the tail."""
     from talkshow_amd import _lib

@@ -53,6 +53,23 @@ def test_pixelcnn_greedy(golden, name):
     np.testing.assert_array_equal(codes, g["codes"])
 
 
+@pytest.mark.parametrize("tag,audio,bh", [("noaud_bh", False, True), ("aud_v", True, False), ("noaud_v", False, False)])
+def test_pixelcnn_variants(golden, tag, audio, bh):
+    """The other constructor variants of GatedPixelCNN (audio=False and / or bh_model=False: `gated_pixelcnn_v2.py:37-42,80-85,
+    137-150`) against the reference's own module (tests/golden/make_golden.py --only pix_variants)."""
+    g = golden("pix_variants")
+    input_dim, dim, n_layers, n_cls, seed = [int(v) for v in g["cfg"]]
+    sd = synth.pixelcnn_state_dict(seed=seed, input_dim=input_dim, dim=dim, n_layers=n_layers, n_classes=n_cls, audio=audio, bh_model=bh)
+    codes = g[tag + "_codes"]
+    H, W = codes.shape[1:]
+    aud = np.repeat(g["aud"].transpose(0, 2, 1)[:, :, :, None], W, axis=3) if audio else None
+    full = O.pixelcnn_forward(codes, g["label"], aud, O.causal_weights(sd, n_layers), n_layers, audio, bh)
+    np.testing.assert_allclose(full.transpose(0, 2, 3, 1), g[tag + "_full_logits"], atol=2e-4, rtol=0)
+    got, logits = O.pixelcnn_generate(g["label"], aud, sd, n_layers, H, return_logits=True, audio=audio, bh_model=bh, W=W)
+    np.testing.assert_allclose(logits, g[tag + "_step_logits"], atol=2e-4, rtol=0)
+    np.testing.assert_array_equal(got, codes)
+
+
 def test_causality(golden):
     """Receptive-field property: logits at (i, j) do not depend on codes at or after (i, j)."""
     g = golden("pix_small")
