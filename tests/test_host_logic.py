@@ -36,6 +36,27 @@ def test_library_exports_every_declared_symbol():
             _lib.context(0)
 
 
+def test_debug_entry_points_have_no_product_callers():
+    """`include/talkshow_hip_debug.h` is for tools/ and tests/: nothing under nets/, evaluation/ or talkshow_amd/ (its ctypes prototype
+    table and the stream helper that forwards an explicit `cus=` request apart) calls an entry point declared there, and the library
+    reads its TS_* test levers in ONE place (api.cpp, at the first ts_ctx_create), never on a launch path."""
+    dbg = set(re.findall(r"\b(ts_[a-z0-9_]+)\s*\(", open(os.path.join(REPO, "include", "talkshow_hip_debug.h")).read()))
+    assert {"ts_debug_skinny_trace", "ts_op_conv1d_timed", "ts_stream_create_cus"} <= dbg
+    for root in ("nets", "evaluation", "talkshow_amd"):
+        for dp, _, files in os.walk(os.path.join(REPO, root)):
+            for f in files:
+                if not f.endswith(".py") or f == "_lib.py":
+                    continue
+                src = open(os.path.join(dp, f)).read()
+                used = [n for n in dbg if n in src]
+                assert not used, f"{dp}/{f} calls debug entry points {used}"
+    csrc = os.path.join(REPO, "talkshow_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".h")) and f != "api.cpp":
+            code = "\n".join(l.split("//")[0] for l in open(os.path.join(csrc, f)).read().splitlines())
+            assert "getenv" not in code, f"{f} reads the environment outside ts::knobs()"
+
+
 def test_no_oracle_import_in_product_code():
     """The oracle is test infrastructure: nothing under talkshow_amd/ or nets/ may import it."""
     for root in ("talkshow_amd", "nets"):
