@@ -190,7 +190,7 @@ def face_block(local):
 
 def frontend_block(w, _lib, clips):
     """The audio front-end on the device (a4 / f1), as extra information: `clips` synthetic 10 s 16 kHz waveforms ->
-    sinc-Hann resample to 22 kHz -> MFCC(64) (`ts_mfcc_forward`: 1.26 GMAC of DFT-as-GEMM per clip), alone and in front of
+    sinc-Hann resample to 22 kHz -> MFCC(64) (`ts_mfcc_forward`: fused framing + real FFT + power kernel, mel / DCT GEMMs), alone and in front of
     one body pass (wav in -> poses out).  The headline's timed region starts from resident MFCC features, as the reference's
     hot path does after `get_mfcc_ta`; this block shows what wav-in costs on top."""
     from talkshow_amd import synth
@@ -214,7 +214,7 @@ def frontend_block(w, _lib, clips):
 
 def wav_in_stability(w, _lib, wav16, ids):
     """Outside any timed region: do the greedy codes depend on WHICH arithmetic produced the MFCC rows?  The same resampled
-    waveforms go through the device MFCC (fp32 DFT-as-GEMM, `ts_mfcc_forward`) and through the float64 host twin
+    waveforms go through the device MFCC (fp32 FFT in LDS, `ts_mfcc_forward`) and through the float64 host twin
     (`frontend.mfcc_float64`); both feature sets then run the same greedy body pass.  Reported: the largest MFCC difference,
     codes that differ (of clips x 150), clips with any difference, the largest pose difference."""
     from talkshow_amd import frontend as FE
@@ -615,8 +615,9 @@ class BodyJob:
         """rank 0's measurement legs beside the headline; no process group is alive while these run"""
         a, w, lib, _lib, eng, B, T, G, S = self.a, self.w, self.lib, self._lib, self.eng, self.B, self.T, self.G, self.S
         mfcc, gt, ids, rank, pool, NB, H = self.mfcc, self.gt, self.ids, self.rank, self.pool, self.NB, self.H
-        # the same workload under the other execution modes, for comparison (not the headline)
-        if not a.no_modes:
+        # the same workload under the other execution modes, for comparison (not the headline); N = 1 only: at N > 1 rank 0 keeps
+        # to the roofline legs so that the job ends soon after the other ranks have left
+        if not a.no_modes and self.world == 1:
             modes = {}
             one = Engine(w, lib, _lib, pool[:1], B, T, 1, mfcc, gt, ids, rank)
             one.warm(1)

@@ -4,8 +4,8 @@
 // restate its published definitions (sinc_interp_hann kernel with lowpass_filter_width 6 / rolloff 0.99; periodic Hann;
 // HTK mel filterbank f_min 0, f_max sr/2, norm None; 10*log10(clamp 1e-10), top_db 80 per clip; orthonormal DCT-II).
 // PARITY UNPINNED against torchaudio; pinned against talkshow_amd/frontend.py (same formulae in numpy) on the GPU.
-// The STFT is a DFT-as-GEMM on conv_gemm_f32 (2048 x 2050 real matrix, [cos | -sin] interleaved): 1.26 GMAC per 10 s
-// clip, exact fp32 MFMA accumulation, no FFT library needed.
+// The STFT is one kernel (framing + window + a radix-4 Stockham real FFT in LDS + |X|^2, mfcc.hip); the mel projection and the
+// DCT are GEMMs on conv_gemm_f32.  (Rounds 1-3 ran the transform as a 2048 x 2050 DFT matrix: 1.26 GMAC per 10 s clip.)
 #include <cmath>
 #include <mutex>
 
@@ -16,11 +16,10 @@ using namespace ts;
 namespace ts {
 hipError_t launch_resample_polyphase(const float *x, int B, int N, const float *kern, int norig, int nnew, int width, int kw,
                                      float *out, int Nout, hipStream_t s);
-hipError_t launch_frame_window(const float *x, int B, int N, int T, int hop, int nfft, const float *win, float *frames,
-                               hipStream_t s);
+hipError_t launch_stft_power(const float *x, int B, int N, int T, int hop, const float *win, const float *tw1024, const float *tw2048,
+                             float *pw, int ldp, hipStream_t s);
 hipError_t launch_resample_kaiser(const float *x, int B, int N, const float *win, const float *delta, int nwin, int num_table,
                                   double ratio, float *out, int Nout, int ldo, hipStream_t s);
-hipError_t launch_power_spectrum(const float *spec, int lds_, int nbins, float *pw, int ldp, long rows, hipStream_t s);
 hipError_t launch_db_topdb(float *mel, int B, long per_clip, float top_db, hipStream_t s);
 }  // namespace ts
 
@@ -28,10 +27,10 @@ struct ts_mfcc {
     ts_ctx *ctx = nullptr;
     int sr_in = 0, sr_out = 0, norig = 1, nnew = 1, width = 0, kw = 0;
     int nfft = 2048, hop = 734, nmels = 256, nmfcc = 64, nbins = 1025, nbins_pad = 1056;
-    DevBuf rs_kern, window;
-    ConvLayer dft, mel, dct;
+    DevBuf rs_kern, window, tw1024, tw2048;   // FFT twiddles: exp(-2 pi i m / 1024), m < 1024; exp(-2 pi i k / 2048), k <= 1024
+    ConvLayer mel, dct;
     struct Work {
-        DevBuf x22, frames, spec, power, melb;
+        DevBuf x22, power, melb;
     };
     StreamWorks<Work> works;
     Work &work(hipStream_t s) { return works.get(s); }
@@ -79,18 +78,20 @@ int ts_mfcc_create(ts_ctx *ctx, int sr_in, int sr_out, int fps, ts_mfcc **out) {
         for (int n = 0; n < m->nfft; ++n) w[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * n / m->nfft));
         TS_TRY(m->window.upload(w.data(), w.size() * sizeof(float)));
     }
-    // ---- DFT matrix rows: (2f) cos(2 pi f n / N), (2f+1) -sin(2 pi f n / N) ----
+    // ---- FFT twiddles, computed in double: the 1024-point complex passes and the real-transform split ----
     {
-        const int N = m->nfft, nb = m->nbins;
-        std::vector<float> w((size_t)2 * nb * N);
-        for (int f = 0; f < nb; ++f)
-            for (int n = 0; n < N; ++n) {
-                const long r = ((long)f * n) % N;          // exact argument reduction
-                const double a = 2.0 * PI * (double)r / N;
-                w[((size_t)2 * f) * N + n] = (float)std::cos(a);
-                w[((size_t)2 * f + 1) * N + n] = (float)(-std::sin(a));
-            }
-        TS_TRY(pack_linear_layer(w.data(), N, nullptr, 2 * nb, N, &m->dft));
+        if (m->nfft != 2048) return fail("ts_mfcc_create: the STFT kernel is built for n_fft = 2048");
+        std::vector<float> a(2 * 1024), bq(2 * 1025);
+        for (int i = 0; i < 1024; ++i) {
+            a[2 * i] = (float)std::cos(2.0 * PI * i / 1024.0);
+            a[2 * i + 1] = (float)(-std::sin(2.0 * PI * i / 1024.0));
+        }
+        for (int i = 0; i <= 1024; ++i) {
+            bq[2 * i] = (float)std::cos(2.0 * PI * i / 2048.0);
+            bq[2 * i + 1] = (float)(-std::sin(2.0 * PI * i / 2048.0));
+        }
+        TS_TRY(m->tw1024.upload(a.data(), a.size() * sizeof(float)));
+        TS_TRY(m->tw2048.upload(bq.data(), bq.size() * sizeof(float)));
     }
     // ---- HTK mel filterbank (torchaudio.functional.melscale_fbanks, norm=None), transposed to [n_mels][n_freqs] ----
     {
@@ -246,19 +247,12 @@ int ts_mfcc_forward(ts_mfcc *m, const float *wav, int B, long N, float *feat, vo
             TS_HIP(launch_resample_polyphase(wav, B, (int)N, m->rs_kern.f(), m->norig, m->nnew, m->width, m->kw, w.x22.f(), (int)N22, s));
             x22 = w.x22.f();
         }
-        TS_TRY(w.frames.ensure((size_t)M * m->nfft * F));
-        TS_HIP(launch_frame_window(x22, B, (int)N22, T, m->hop, m->nfft, m->window.f(), w.frames.f(), s));
+        // framing + window + 2048-point real FFT + |X|^2 in one kernel (mfcc.hip::stft_power_kernel)
+        TS_TRY(w.power.ensure((size_t)M * m->nbins_pad * F));
+        TS_HIP(launch_stft_power(x22, B, (int)N22, T, m->hop, m->window.f(), m->tw1024.f(), m->tw2048.f(), w.power.f(), m->nbins_pad, s));
     }
-    TS_TRY(w.spec.ensure((size_t)M * 2 * m->nbins * F));
-    TS_TRY(w.power.ensure((size_t)M * m->nbins_pad * F));
     TS_TRY(w.melb.ensure((size_t)M * m->nmels * F));
     ConvParams p;
-    conv_layer_params(m->dft, w.frames.f(), m->nfft, 1, (int)M, nullptr, 0, w.spec.f(), 2 * m->nbins, 0, 2 * m->nbins, &p);
-    TS_TRY(run_conv(ctx, p, 0, s));
-    {
-        MiscScope ms(ctx, s);
-        TS_HIP(launch_power_spectrum(w.spec.f(), 2 * m->nbins, m->nbins, w.power.f(), m->nbins_pad, M, s));
-    }
     conv_layer_params(m->mel, w.power.f(), m->nbins_pad, 1, (int)M, nullptr, 0, w.melb.f(), m->nmels, 0, m->nmels, &p);
     TS_TRY(run_conv(ctx, p, 0, s));
     {

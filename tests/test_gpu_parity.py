@@ -923,7 +923,7 @@ def test_error_behaviour(hip):
 
 
 def test_device_mfcc_vs_host_restatement(hip, tmp_path):
-    """ts_mfcc_* (polyphase resample + DFT-as-GEMM + mel + dB/top_db + DCT on the GPU) against the numpy restatement of
+    """ts_mfcc_* (polyphase resample + fused STFT kernel (real FFT in LDS) + mel + dB/top_db + DCT on the GPU) against the numpy restatement of
     the same torchaudio definitions (talkshow_amd/frontend.py; both unpinned against torchaudio itself)."""
     from scipy.io import wavfile
     from talkshow_amd import frontend as fe
@@ -937,7 +937,7 @@ def test_device_mfcc_vs_host_restatement(hip, tmp_path):
         x22 = fe.resample_sinc_hann(w_[None], 16000, 22000)[0]
         ref = fe.mfcc(x22, 22000, hop_length=734).T
         assert dev[i].shape == ref.shape == (300 if len(x22) // 734 + 1 == 300 else len(x22) // 734 + 1, 64)
-        # coefficients are O(10..200); fp32 DFT-as-GEMM vs pocketfft differ by summation order only: the device rows sit within
+        # coefficients are O(10..200); the device's fp32 radix-4 FFT vs pocketfft differ by rounding only: the device rows sit within
         # 2e-4 of the float64 twin (test_wav_in_code_stability), the float32 twins within 2e-4 of it too; 2e-3 is the bound
         np.testing.assert_allclose(dev[i], ref, atol=2e-3, rtol=2e-4)
     # no resampling branch + the wav-file entry point used by infer_on_audio
@@ -959,7 +959,7 @@ def test_device_mfcc_vs_host_restatement(hip, tmp_path):
 
 
 def test_wav_in_code_stability(hip, tmp_path):
-    """device MFCC rows (fp32 DFT-as-GEMM) vs the float64 host twin on the same resampled waveforms — the MFCC
+    """device MFCC rows (fp32 FFT) vs the float64 host twin on the same resampled waveforms — the MFCC
     difference stays under 2e-3 (coefficients are O(10..200)) and NOT ONE of the 32 x 150 greedy codes changes, for noise clips
     (the bench's synthetic audio) and for speech-like clips (amplitude-modulated harmonics + noise, 50 dB of dynamic range)."""
     import bench
