@@ -128,6 +128,7 @@ int ts_pixelcnn_v_generate(ts_pixelcnn_v *p, const int64_t *label, const float *
     while ((1 << wshift) < W) ++wshift;
     if (W < 1 || (1 << wshift) != W || W > 64) return fail("ts_pixelcnn_v_generate: the grid width must be a power of two <= 64");
     if (mode == TS_SAMPLE_UNIFORMS && !uniforms) return fail("ts_pixelcnn_v_generate: uniforms required");
+    if ((long)B * W > 4096) return fail("ts_pixelcnn_v_generate: B * W exceeds 4096 rows per stage (the chain kernels' limit): split the call");
     hipStream_t s = (hipStream_t)stream;
     ts_ctx *ctx = p->ctx;
     const int D = p->D, NL = p->NL, V = p->V, M = B * W, HID = p->HID;
