@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][pa_][i], fb[slot][pb_][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[slot][pb_][j], fa[slot][pa_][i], acc[i][j], 0, 0, 0);
             }
     };
     const int nchunks = p.Ktot / BK;
@@ -257,34 +257,63 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p
     }
 
     // ---- epilogue: bias (+ residual) + activation, masked store ----
-    // the 16 residual values of an accumulator block are fetched together, ahead of their use (one load-to-use round trip per
-    // block instead of one per element: the stack-tail layers ran 4-33 % slower than their residual-free neighbours)
+    // The MFMA operands are swapped (weights as A, activations as B: the same products in the same k order, the same bits), so an
+    // accumulator block holds D[channel][row]: lane (li, lh) owns output row m = li and, per group g of 4 registers, the 4
+    // CONSECUTIVE channels 8 g + 4 lh .. + 3 — bias, residual and output move as 16-byte vectors (4 stores per 32 x 32 block
+    // instead of 16; the residual values of a block are fetched together, ahead of their use).  Rows / buffers that are not
+    // 16-byte aligned (the 39- / 90- / 129-wide pose rows) and channel tails take the scalar form.
+    const bool vec_out = ((p.ldo | g.out_col0) & 3) == 0 && (reinterpret_cast<uintptr_t>(gout) & 15) == 0;
+    const bool vec_res = gres && (p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(gres) & 15) == 0;
+    const bool vec_bias = gbias && (reinterpret_cast<uintptr_t>(gbias) & 15) == 0;
+    auto activate = [&](float v, float rvv) {
+        if (gres && !p.res_after_act) v += rvv;
+        if (p.act == 1) v = v >= 0.f ? v : v * 0.2f;
+        else if (p.act == 2) v = v > 0.f ? v : 0.f;
+        else if (p.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        if (gres && p.res_after_act) v += rvv;
+        return v;
+    };
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + li;
-        const float bv = gbias ? gbias[n] : 0.f;
-        const bool nok = n < p.N;
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WM + i * 32 + li;
+        const bool mok = m < p.M;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float rv[16];
-            if (gres) {
+        for (int j = 0; j < TN; ++j) {
+            const int nb0 = n0 + wn * WN + j * 32 + 4 * lh;
+            f32x4 rv[4], bv[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    rv[r] = (nok && m < p.M) ? gres[(long)m * p.ldr + n] : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const int nb = nb0 + 8 * q;
+                const bool full = nb + 3 < p.N;
+                bv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (gbias) {
+                    if (vec_bias && full) bv[q] = *reinterpret_cast<const f32x4 *>(gbias + nb);
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bv[q][r] = nb + r < p.N ? gbias[nb + r] : 0.f;
+                }
+                rv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (gres && mok) {
+                    const float *rp = gres + (long)m * p.ldr + nb;
+                    if (vec_res && full) rv[q] = *reinterpret_cast<const f32x4 *>(rp);
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rv[q][r] = nb + r < p.N ? rp[r] : 0.f;
                 }
             }
+            if (mok) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (nok && m < p.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (gres && !p.res_after_act) v += rv[r];
-                    if (p.act == 1) v = v >= 0.f ? v : v * 0.2f;
-                    else if (p.act == 2) v = v > 0.f ? v : 0.f;
-                    else if (p.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (gres && p.res_after_act) v += rv[r];
-                    gout[(long)m * p.ldo + g.out_col0 + n] = v;
+                for (int q = 0; q < 4; ++q) {
+                    const int nb = nb0 + 8 * q;
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = activate(acc[i][j][4 * q + r] + bv[q][r], rv[q][r]);
+                    float *op = gout + (long)m * p.ldo + g.out_col0 + nb;
+                    if (vec_out && nb + 3 < p.N) *reinterpret_cast<f32x4 *>(op) = v;
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (nb + r < p.N) op[r] = v[r];
                 }
             }
         }
