@@ -255,7 +255,6 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
         L[i + 1] = (L[i] - f->fc_k[i]) / 2 + 1;
         if (L[i] < f->fc_k[i]) return fail("ts_face_generate: audio too short (needs >= 400 samples)");
     }
-    if ((long)B * f->HEADS > 65535) return fail("ts_face_generate: B * heads exceeds the attention grid (65 535): split the call");
     const long M = (long)B * T;
     ts_face::Work &w = f->work(s);
     const size_t F = sizeof(float);

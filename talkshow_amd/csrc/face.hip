@@ -184,8 +184,7 @@ hipError_t launch_lerp_ln(const float *x, int B, int Lin, int T, const float *ga
 
 // ---- fused attention of one wav2vec2 encoder layer (HF eager_attention_forward: softmax(Q K^T * d^-0.5) V, wav2vec.py:76-143) ----
 // One workgroup = 64 queries of one (clip, head); wave w owns queries 16 w .. 16 w + 15 and walks the keys in tiles of 64 that all
-// four waves share through LDS (K as [key][d], V transposed to [d][key], rows pitched 68 floats: every ds_read_b128 of an operand
-// fragment is conflict-free).  Both products run on v_mfma_f32_16x16x4_f32 with the KEYS as the rows of the first product:
+// four waves share through LDS (K and V as [key][d], rows pitched 68 floats).  Both products run on v_mfma_f32_16x16x4_f32 with the KEYS as the rows of the first product:
 //     S^T[key][query] = K Q^T        lane (li, lg) ends up with keys 4 lg .. 4 lg + 3 of each 16-key block for query li
 //     O^T[d][query]  += V^T P^T      ... which is exactly the B-operand fragment of the second product (k index = key 4 lg + e)
 // so the probabilities never leave their registers, a query's running max / sum are two xor-shuffles across the four lane groups,
@@ -193,27 +192,49 @@ hipError_t launch_lerp_ln(const float *x, int B, int Lin, int T, const float *ga
 // 0.77 GB written and read back per layer at batch 64) does not exist.  Online soft-max over the key tiles (running max m, sum l,
 // O rescaled by exp(m_old - m_new)): any T, no 2^31-entry score buffer.  fp32 throughout; the scale 2^-3 is exact.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int V> struct IC4 { static constexpr int value = V; };
 constexpr int ATT_P = 68;
-__global__ __launch_bounds__(256, 2) void attention_kernel(const float *__restrict__ qkv, int T, int HID, int heads, float scale,
+// all-reduce across the four 16-lane rows of a wave with the gfx950 row-swap instructions (VALU; a __shfl_xor is a ds_bpermute: an LDS
+// round trip on the soft-max's critical path): v_permlane16_swap(x, x) -> {rows (0,0,2,2), rows (1,1,3,3)}, v_permlane32_swap(x, x) ->
+// {lower half twice, upper half twice}
+template <class Op> __device__ __forceinline__ float rows_allreduce(float x, Op op) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return op(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float *__restrict__ qkv, int T, int HID, int heads, int nz, float scale,
                                                            float *__restrict__ out) {
     __shared__ float Ks[64 * ATT_P];
-    __shared__ float Vt[64 * ATT_P];
+    __shared__ float Vs[64 * ATT_P];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    const int z = blockIdx.y, b = z / heads, h = z - b * heads;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    // workgroup id -> (clip-head z, query tile): consecutive ids go to consecutive XCDs, so the nq query tiles of one (clip, head)
+    // take ids that are congruent mod 8 — they run on ONE XCD, back to back, and find K / V of their (clip, head) in its L2
+    // (with the query tile as the fastest grid index every tile of a (clip, head) pulled its own copy over the fabric:
+    // 708 MB per launch at batch 64 against 236 MB of compulsory traffic)
+    const int nq = (T + 63) >> 6;
+    const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
+    const int z = (grp / nq) * 8 + xcd;
+    if (z >= nz) return;
+    const int b = z / heads, h = z - b * heads;
+    const int q0 = (grp % nq) * 64 + wave * 16;
     const long ld = 3L * HID;
     const float *base = qkv + (long)b * T * ld + h * 64;
-    // Q fragments, B operand of the first product: lane (li, lg) holds Q[q0 + li][16 qs + 4 lg + e]; rows past T are clamped (computed, never stored)
+    // soft-max in base 2: exp(s * scale - max) = 2^(s * scale * log2 e - max'), one v_exp_f32 per probability instead of expf's
+    // range reduction (32 of them per lane and key tile: as many VALU slots as the tile's MFMAs have issue slots)
+    const float scale2 = scale * 1.44269504088896341f;
+    // Q fragments (pre-multiplied by scale * log2 e), B operand of the first product: lane (li, lg) holds Q[q0 + li][16 qs + 4 lg + e]; rows past T are clamped (computed, never stored)
     f32x4 qf[4];
     {
         const int qrow = q0 + li < T ? q0 + li : T - 1;
 #pragma unroll
-        for (int qs = 0; qs < 4; ++qs) qf[qs] = *reinterpret_cast<const f32x4 *>(base + (long)qrow * ld + 16 * qs + 4 * lg);
+        for (int qs = 0; qs < 4; ++qs) qf[qs] = *reinterpret_cast<const f32x4 *>(base + (long)qrow * ld + 16 * qs + 4 * lg) * scale2;
     }
     f32x4 o[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
+    const bool live = q0 < T;   // wave-uniform: this wave has at least one real query (it still stages K / V and meets the barriers)
     for (int k0 = 0; k0 < T; k0 += 64) {
         __syncthreads();   // every wave is done reading the previous tile
 #pragma unroll
@@ -225,60 +246,78 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float *__restri
                 vv = *reinterpret_cast<const f32x4 *>(base + (long)key * ld + 2 * HID + col);
             }
             *reinterpret_cast<f32x4 *>(&Ks[row * ATT_P + col]) = kv;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) Vt[(col + c) * ATT_P + row] = vv[c];
+            *reinterpret_cast<f32x4 *>(&Vs[row * ATT_P + col]) = vv;
         }
         __syncthreads();
-        // S^T = K Q^T: 4 key blocks x (4 q-steps x 4) MFMAs
-        f32x4 sacc[4];
+        // The products of one key tile for NKB real 16-key blocks (compile-time: the MFMA stream has no branches in it).  The key block /
+        // d block is the INNER loop of both products: four independent accumulators take turns, so an MFMA never waits for its
+        // predecessor's result (16 in a row on one accumulator issue every 40 cycles, not 32).  Key blocks wholly beyond T (the last
+        // tile of a 300-frame clip has three real blocks) are not multiplied, nor are waves whose 16 queries all lie beyond T.
+        auto tile = [&](auto NKBc, auto RAGc) {
+            constexpr int NKB = decltype(NKBc)::value;
+            constexpr bool RAGGED = decltype(RAGc)::value != 0;   // the tile reaches beyond T: its padding keys are masked
+            f32x4 sacc[NKB];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < NKB; ++kb) sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int qs = 0; qs < 4; ++qs) {
-                const f32x4 kf = *reinterpret_cast<const f32x4 *>(&Ks[(kb * 16 + li) * ATT_P + 16 * qs + 4 * lg]);
+                f32x4 kf[NKB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[qs][e], sacc[kb], 0, 0, 0);
+                for (int kb = 0; kb < NKB; ++kb) kf[kb] = *reinterpret_cast<const f32x4 *>(&Ks[(kb * 16 + li) * ATT_P + 16 * qs + 4 * lg]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kb][e], qf[qs][e], sacc[kb], 0, 0, 0);
             }
+            // scale, mask the padding keys, online soft-max of query li (this lane's keys: k0 + 16 kb + 4 lg + r)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (RAGGED && (k0 + kb * 16 + 4 * lg + r) >= T) sacc[kb][r] = -INFINITY;
+                    mx = fmaxf(mx, sacc[kb][r]);
+                }
+            mx = rows_allreduce(mx, [](float a, float b) { return fmaxf(a, b); });
+            const float m_new = fmaxf(m, mx);          // finite: every tile holds at least one real key
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);       // first tile: 2^-inf = 0
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - m_new);
+                    sacc[kb][r] = pv;
+                    rs += pv;
+                }
+            rs = rows_allreduce(rs, [](float a, float b) { return a + b; });
+            l = l * alpha + rs;
+            m = m_new;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[db] *= alpha;
+            // O^T += V^T P^T; the B operand is the probability registers as they are.  The A operand V^T[d = li][key = 4 lg + e] is read
+            // from V as it was staged ([key][d], 16 consecutive d per lane group: four ds_read_b32, rows 4 lg + e of a 68-float pitch
+            // land 16 banks apart for lg and lg + 1: conflict-free) — a transposed copy of V would need 16 scattered ds_write_b32 per
+            // thread and tile, 8 lanes to a bank (measured: 63 % of the LDS cycles were conflicts)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float va[4];
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) va[db] = Vs[(kb * 16 + 4 * lg + e) * ATT_P + db * 16 + li];
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[db], sacc[kb][e], o[db], 0, 0, 0);
+                }
+        };
+        if (live) {
+            const int nkb = (T - k0 + 15) >> 4;
+            if (k0 + 64 <= T) tile(IC4<4>{}, IC4<0>{});
+            else if (nkb >= 4) tile(IC4<4>{}, IC4<1>{});
+            else if (nkb == 3) tile(IC4<3>{}, IC4<1>{});
+            else if (nkb == 2) tile(IC4<2>{}, IC4<1>{});
+            else tile(IC4<1>{}, IC4<1>{});
         }
-        // scale, mask the padding keys, online soft-max of query li (this lane's keys: k0 + 16 kb + 4 lg + r)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sv = (k0 + kb * 16 + 4 * lg + r) < T ? sacc[kb][r] * scale : -INFINITY;
-                sacc[kb][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m, mx);          // finite: every tile holds at least one real key
-        const float alpha = expf(m - m_new);       // first tile: exp(-inf) = 0
-        float rs = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = expf(sacc[kb][r] - m_new);
-                sacc[kb][r] = pv;
-                rs += pv;
-            }
-        rs += __shfl_xor(rs, 16);
-        rs += __shfl_xor(rs, 32);
-        l = l * alpha + rs;
-        m = m_new;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) o[db] *= alpha;
-        // O^T += V^T P^T: 4 d blocks x 4 key blocks x 4 MFMAs; the B operand is the probability registers as they are
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const f32x4 vf = *reinterpret_cast<const f32x4 *>(&Vt[(db * 16 + li) * ATT_P + kb * 16 + 4 * lg]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], sacc[kb][e], o[db], 0, 0, 0);
-            }
     }
     if (q0 + li < T) {
         const float inv = 1.0f / l;
@@ -289,8 +328,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float *__restri
 }
 // qkv (B, T, 3 HID) rows [q | k | v], heads of 64 channels -> out (B, T, HID) = concatenated heads' softmax(q k^T * scale) v
 hipError_t launch_attention(const float *qkv, int B, int T, int HID, int heads, float scale, float *out, hipStream_t s) {
-    if (HID != heads * 64 || B < 1 || T < 1 || (long)B * heads > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attention_kernel, dim3((T + 63) / 64, B * heads), dim3(256), 0, s, qkv, T, HID, heads, scale, out);
+    if (HID != heads * 64 || B < 1 || T < 1 || (long)B * heads * ((T + 63) / 64) > (1l << 30)) return hipErrorInvalidValue;
+    const int nq = (T + 63) / 64, nz = B * heads;
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(((nz + 7) / 8) * 8 * nq)), dim3(256), 0, s, qkv, T, HID, heads, nz, scale, out);
     return hipGetLastError();
 }
 

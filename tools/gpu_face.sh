@@ -9,6 +9,6 @@ sys.path.insert(0, '.')
 import bench, torch
 torch.cuda.set_device(0)
 f = bench.face_block(0)
-print(json.dumps({k: f[k] for k in ('frames_per_s', 'ms_per_batch', 'conv_gemm_f32', 'other_kernels_ms')}))
+print(json.dumps({k: f[k] for k in ('frames_per_s', 'ms_per_batch', 'conv_gemm_f32', 'attention_fused', 'other_kernels_ms')}))
 print(json.dumps(f['split_bf16']))
 PY
