@@ -25,8 +25,40 @@ __global__ void resample_polyphase_kernel(const float *__restrict__ x, int N, co
     }
     out[(long)b * Nout + j] = acc;
 }
+// The same sum with the polyphase table and the block's input window staged in LDS (the plain kernel fetches 2 kw values per output
+// through L1: 58 % of the front-end once the STFT became an FFT).  Same terms in the same order — taps that fall outside the clip
+// multiply a staged zero instead of being skipped, which leaves the fma chain's value unchanged — so the samples are bit-identical.
+__global__ __launch_bounds__(256) void resample_polyphase_lds_kernel(const float *__restrict__ x, int N, const float *__restrict__ kern,
+                                                                     int norig, int nnew, int width, int kw, float *__restrict__ out,
+                                                                     int Nout, int nwin) {
+    extern __shared__ float sm[];
+    float *sk = sm, *sw = sm + nnew * kw;
+    const int b = blockIdx.y, j0 = blockIdx.x * 256;
+    const float *xb = x + (long)b * N;
+    const int base = (j0 / nnew) * norig - width;            // first input sample any output of this block touches
+    for (int i = threadIdx.x; i < nnew * kw; i += 256) sk[i] = kern[i];
+    for (int i = threadIdx.x; i < nwin; i += 256) {
+        const int g = base + i;
+        sw[i] = (g >= 0 && g < N) ? xb[g] : 0.f;
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    if (j >= Nout) return;
+    const int wdw = j / nnew, ph = j - wdw * nnew;
+    const float *kr = sk + ph * kw, *xw = sw + (wdw * norig - width - base);
+    float acc = 0.f;
+    for (int k = 0; k < kw; ++k) acc = fmaf(kr[k], xw[k], acc);
+    out[(long)b * Nout + j] = acc;
+}
 hipError_t launch_resample_polyphase(const float *x, int B, int N, const float *kern, int norig, int nnew, int width, int kw,
                                      float *out, int Nout, hipStream_t s) {
+    const int nwin = (255 / nnew + 1) * norig + kw;          // input window of 256 consecutive outputs
+    const size_t lds = ((size_t)nnew * kw + nwin) * sizeof(float);
+    if (lds <= 48 * 1024) {   // small rate ratios (16 k -> 22 k: 11 x 22 taps); big ones (44.1 k -> 22 k: 220 x 467) keep the plain kernel
+        hipLaunchKernelGGL(resample_polyphase_lds_kernel, dim3((Nout + 255) / 256, B), dim3(256), lds, s, x, N, kern, norig, nnew, width,
+                           kw, out, Nout, nwin);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(resample_polyphase_kernel, dim3((Nout + 255) / 256, B), dim3(256), 0, s, x, N, kern, norig, nnew, width,
                        kw, out, Nout);
     return hipGetLastError();

@@ -1110,6 +1110,22 @@ def test_feature_stats_large_and_ragged(hip):
         E.FeatureStats(48).push(np.zeros((4, 48), np.float32))
 
 
+@pytest.mark.parametrize("sr_in", [16000, 24000, 44100, 8000])
+def test_device_sinc_hann_resampler_vs_twin(hip, sr_in):
+    """`ts_mfcc_resample` (torchaudio's sinc-Hann polyphase FIR; `data_utils/utils.py:150-152`) against the numpy twin for the sample
+    rates of the reference's demo wavs (16 k, 24 k -> the LDS-staged kernel), 44.1 k (220 x 467-tap table: the plain kernel) and an
+    up-sampling ratio; two clips of different content, a length that is not a multiple of the block."""
+    from talkshow_amd import frontend as fe
+    from talkshow_amd.modules import MFCC
+    rng = np.random.default_rng(sr_in)
+    n = sr_in * 2 + 37
+    x = (0.3 * rng.standard_normal((2, n))).astype(np.float32)
+    got = MFCC(sr_in, 22000, 30).resample(x).cpu().numpy()
+    ref = fe.resample_sinc_hann(x, sr_in, 22000)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, atol=2e-6, rtol=0)
+
+
 def test_device_kaiser_resampler_and_sepa(hip, tmp_path):
     """ts_resample_kaiser (face path: librosa.load(sr=16000)'s resampler) and the device get_mfcc_sepa against their numpy
     twins in talkshow_amd/frontend.py (both restate third-party definitions; the resamplers are unpinned against
