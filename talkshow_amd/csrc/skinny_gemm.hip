@@ -147,7 +147,7 @@ __global__ __launch_bounds__(W * 64) void skinny_gemm_kernel(const SkinnyBatch b
             v += e_cls[rr];
             const float partner = __shfl_xor(v, 16);
             if ((li & 16) == 0 && ok) {
-                const float gate = tanhf(v) * (1.0f / (1.0f + expf(-partner)));
+                const float gate = gate_act(v, partner);
                 const int tiles_per_group = p.gateD >> 4;
                 const int group = tile / tiles_per_group, ch0 = (tile - group * tiles_per_group) << 4;
                 p.out[(long)row * p.out_stride + group * p.gateD + ch0 + (li & 15)] = gate;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(W * 64) void skinny16_kernel(const SkinnyBatch batc
             v += e_cls[rr];
             const float partner = __shfl_xor(v, 8);
             if ((li & 8) == 0 && ok) {
-                const float gate = tanhf(v) * (1.0f / (1.0f + expf(-partner)));
+                const float gate = gate_act(v, partner);
                 const int tiles_per_group = p.gateD >> 3;
                 const int group = tile / tiles_per_group, ch0 = (tile - group * tiles_per_group) << 3;
                 p.out[(long)row * p.out_stride + group * p.gateD + ch0 + (li & 7)] = gate;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(W * 64, (RB * CB > 8 ? W / 4 : (RB * CB > 4 ? W / 2
             v += e_cls[rr];
             const float partner = __shfl_xor(v, 8);
             if ((li & 8) == 0 && ok) {
-                const float g = tanhf(v) * (1.0f / (1.0f + expf(-partner)));
+                const float g = gate_act(v, partner);
                 const int t16 = tile * CB + cb;
                 const int tiles_per_group = gateD >> 3;
                 const int group = sdiv(t16, tiles_per_group), ch0 = (t16 - group * tiles_per_group) << 3;

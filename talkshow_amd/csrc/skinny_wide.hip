@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void skinny16_wide_kernel(const SkinnyDescB
                 if (lg < 2 && m_ok) {
                     f32x4 g;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) g[r] = tanhf(v[r]) * (1.0f / (1.0f + expf(-partner[r])));
+                    for (int r = 0; r < 4; ++r) g[r] = gate_act(v[r], partner[r]);
                     const long io = (long)mrow * out_stride + oc[cb];
                     *reinterpret_cast<gf4 *>(out + (out_tw ? tiled_index(io, out_tw) : io)) = g;
                 }
