@@ -19,14 +19,32 @@ namespace ts {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;   // LDS-qualified: volatile accesses must not fall back to flat
+
+// Scheduling hints for one half of a chunk (see the main loop): behind each of the MF MFMAs its share of the VALU work, of the NDS LDS
+// operations and one of the NVM global loads.  sched_group_barrier wants literal arguments, hence the recursion.
+template <int MASK, int N>
+__device__ __forceinline__ void sched_group() {
+    if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+}
+template <int MF, int VPM, int NDS, int NVM, int K = 0>
+__device__ __forceinline__ void deal_hints() {
+    if constexpr (K < MF) {
+        sched_group<0x008, 1>();                                  // one MFMA
+        sched_group<0x002, VPM>();                                // VALU
+        sched_group<0x080, (K + 1) * NDS / MF - K * NDS / MF>();  // LDS
+        sched_group<0x020, (K < NVM ? 1 : 0)>();                  // global load
+        deal_hints<MF, VPM, NDS, NVM, K + 1>();
+    }
+}
 
 template <int BM, int BN, int WM, int WN, int NP>
 __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p) {
     constexpr int BK = 32;
     constexpr int LDS_LD = 20;       // dwords per LDS row: 32 bf16 (16 dwords) + 4 of padding -> 80 B pitch, conflict-free for ds_read_b128
-    constexpr int KC = 1;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int PA = BM / 32, PB = BN / 32;   // 32-row load passes per operand
@@ -52,10 +70,38 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // Which tile?  With three bf16 products per fp32 product this kernel moves its operands 2.4 x faster than conv_gemm_f32, and the
+    // counters (profiles/r04_notes/split_bound.txt) show what that ran into: 7.6 TB/s over the fabric, L2 hit rate 58 % — in the plain
+    // grid a tile's neighbours along N sit on other XCDs and every XCD's L2 fetches its own copy of the operands.  So the launcher asks for a
+    // 1-D grid: workgroup ids go round-robin over the 8 XCDs, XCD x takes the x-th contiguous eighth of the tile list, and the list runs
+    // through column groups of 8 tiles, rows inside a group, columns fastest — the 64 workgroups resident on an XCD are 8 x 8 tiles that
+    // share 8 A and 8 B tiles in its L2, an A tile is fetched by one XCD per column group, a B group once per XCD that touches it.
+    // L2 hit rate 0.58 -> 0.82, fabric traffic -64 %, face batch 32.4 -> 29.7 ms; the same tiles, the same bits.
+    int tx = blockIdx.x, ty = blockIdx.y;
+    if (p.xcd_tiles) {   // = the column-group width
+        const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN, total = MT * NT;
+        const int per = (total + 7) >> 3;
+        const int L = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+        if (L >= total) return;
+        const int GW = p.xcd_tiles;   // column-group width in tiles
+        const int full = NT / GW;
+        int g8 = L / (MT * GW), r = L - g8 * MT * GW, gn = GW;
+        if (g8 >= full) {   // the last, narrower column group
+            g8 = full;
+            r = L - full * MT * GW;
+            gn = NT - GW * full;
+        }
+        tx = r / gn;
+        ty = g8 * GW + (r - tx * gn);
+    }
+    const int m0 = tx * BM, n0 = ty * BN;
 
     // ---- per-thread global-load geometry: row (tid/8) of each 32-row pass, float4 column (tid%8) ----
-    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+    // Rows are dealt to the 8-thread groups so that the two rows of a 16-lane group are 4 apart: ds_write_b64 is serviced in contiguous
+    // 16-lane groups with banks (a / 4) mod 32, and with the 20-dword pitch rows r and r + 1 share 4 banks (2-way conflict in every
+    // group: a third of this kernel's LDS cycles, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.333) while rows r and r + 4 are 16 banks apart.
+    const int lg = tid >> 3;
+    const int lrow = ((lg & 1) << 2) | ((lg >> 1) & 3) | (lg & 24), lc4 = (tid & 7) * 4;
     long a_rowbase[PA];   // (b*Lin) input row base, or -1 if the output row is out of range
     int a_t[PA];          // t*stride
 #pragma unroll
@@ -120,10 +166,9 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p
     enter_run();
 #pragma unroll
     for (int i = 0; i < PB; ++i) pb[i] = n0 + i * 32 + lrow < w_rows ? wbase + (long)i * 32 * ldw : zero;
-    auto advance = [&]() {
+    // The A and the B half of a chunk move separately (see the loop below): A walks taps / segments, B walks its rows
+    auto advance_a = [&]() {
         cc += 1;
-#pragma unroll
-        for (int i = 0; i < PB; ++i) pb[i] += BK;
         if (cc * BK >= cur_len) {   // wave-uniform: next tap or next segment
             cc = 0;
             tap += 1;
@@ -137,16 +182,18 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p
             for (int i = 0; i < PA; ++i) pa[i] += BK;
         }
     };
-    f32x4 ra[PA][KC], rb[PB][KC];
-    auto load_chunk = [&]() {
+    auto advance_b = [&](int by) {
 #pragma unroll
-        for (int i = 0; i < PA; ++i)
+        for (int i = 0; i < PB; ++i) pb[i] += by;
+    };
+    f32x4 ra[PA], rb[PB];
+    auto load_a = [&](f32x4 (&r)[PA]) {
 #pragma unroll
-            for (int c = 0; c < KC; ++c) ra[i][c] = *reinterpret_cast<const f32x4 *>(pa[i] + c * 32);
+        for (int i = 0; i < PA; ++i) r[i] = *reinterpret_cast<const f32x4 *>(pa[i]);
+    };
+    auto load_b = [&](f32x4 (&r)[PB]) {
 #pragma unroll
-        for (int i = 0; i < PB; ++i)
-#pragma unroll
-            for (int c = 0; c < KC; ++c) rb[i][c] = *reinterpret_cast<const f32x4 *>(pb[i] + c * 32);
+        for (int i = 0; i < PB; ++i) r[i] = *reinterpret_cast<const f32x4 *>(pb[i]);
     };
     // fp32 registers -> NP bf16 planes in LDS (8 bytes per plane per thread and row): the split happens HERE, so the operands
     // stay fp32 in HBM and no layer needs to know about the arithmetic plan of its neighbours
@@ -154,9 +201,9 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p
         float r0 = x[0], r1 = x[1], r2 = x[2], r3 = x[3];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
-            uint32_t p01, p23;
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p01) : "v"(r0), "v"(r1));
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p23) : "v"(r2), "v"(r3));
+            // v_cvt_pk_bf16_f32 (round to nearest even), through the conversion builtin so that the scheduler sees a VALU instruction
+            const uint32_t p01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+            const uint32_t p23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r2, r3}, bf16x2));
             out[pl] = uint2{p01, p23};
             if (pl + 1 < NP) {
                 r0 -= __builtin_bit_cast(float, p01 << 16);
@@ -166,19 +213,22 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p
             }
         }
     };
-    auto store_chunk = [&](int buf) {
-        uint2 s[NP];
+    auto store_a = [&](int buf, const f32x4 (&r)[PA]) {
+        uint2 sp[NP];
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            split4(ra[i][0], s);
+            split4(r[i], sp);
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2 *>(&As[buf][pl][i * 32 + lrow][lc4 >> 1]) = s[pl];
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2 *>(&As[buf][pl][i * 32 + lrow][lc4 >> 1]) = sp[pl];
         }
+    };
+    auto store_b = [&](int buf, const f32x4 (&r)[PB]) {
+        uint2 sp[NP];
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            split4(rb[i][0], s);
+            split4(r[i], sp);
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2 *>(&Bs[buf][pl][i * 32 + lrow][lc4 >> 1]) = s[pl];
+            for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<uint2 *>(&Bs[buf][pl][i * 32 + lrow][lc4 >> 1]) = sp[pl];
         }
     };
     // fragments of one k-step of 16: lane (li, lh) holds k = 8 lh .. 8 lh + 7 of row li, for every plane
@@ -210,49 +260,59 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[slot][pb_][j], fa[slot][pa_][i], acc[i][j], 0, 0, 0);
             }
     };
+    // ================= main loop =================
+    // A v_mfma_f32_32x32x16_bf16 occupies the pipe for 32 cycles = 8 issue slots, and a chunk carries 24 of them next to ~170 other
+    // instructions per wave (111 VALU of the split, 8 + 16 LDS, 8 loads, scalar bookkeeping).  The round-3 form converted and stored a whole
+    // chunk ahead of its first MFMAs (~95 VALU in a row with ONE MFMA in flight, then 12 MFMAs back to back behind the barrier); here the
+    // chunk is cut in two equal halves around its barrier and each half carries the same side work:
+    //   first half   MFMAs of k-step 0 | B of chunk c + 1: registers -> planes -> LDS, B of chunk c + 2 -> registers | fragments of k-step 1
+    //   barrier
+    //   second half  MFMAs of k-step 1 | A of chunk c + 2: registers -> planes -> LDS (the buffer chunk c just left), A of chunk c + 3 ->
+    //                registers | fragments of k-step 0 of chunk c + 1
+    // and inside a half sched_group_barrier deals the side work out behind the MFMAs.  Same products, same order: same bits.  Measured
+    // (profiles/r04_notes/split_bound.txt): the even interleave alone is worth 1.5 %; the matrix pipe stays 40 % busy with nothing saturated.
+    static_assert(NQ == 2, "two k-steps per chunk");
+    constexpr int MF = TM * TN * (NP == 2 ? 3 : 6);           // MFMAs per k-step
+    constexpr int VALU_HALF = (PA > PB ? PA : PB) * (NP == 2 ? 12 : 22) + 8;
+    constexpr int VPM = (VALU_HALF + MF - 1) / MF;
     const int nchunks = p.Ktot / BK;
-    load_chunk();
-    store_chunk(0);
-    if (nchunks > 1) {
-        advance();
-        load_chunk();
+    int buf = 0;
+    {   // prologue: chunk 0 -> buffer 0, A of chunk 1 -> buffer 1, B of chunk 1 and A of chunk 2 -> registers
+        f32x4 ra0[PA], rb0[PB];
+        load_a(ra0);
+        load_b(rb0);
+        if (nchunks > 1) {
+            advance_a();
+            advance_b(BK);
+            load_a(ra);
+            load_b(rb);
+        }
+        store_a(0, ra0);
+        store_b(0, rb0);
+        if (nchunks > 1) store_a(1, ra);
+        if (nchunks > 2) {
+            advance_a();
+            load_a(ra);
+        }
     }
     __syncthreads();
     read_frags(0, 0, 0);
-    int buf = 0;
-    int it = 0;
-    for (; it + 2 < nchunks; ++it) {   // steady state: chunk it+1 -> LDS, chunk it+2 -> registers, MFMAs of chunk it
-        advance();
-        store_chunk(buf ^ 1);
-        load_chunk();
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (q + 1 < NQ) {
-                read_frags(buf, q + 1, (q + 1) & 1);
-            } else {
-                __syncthreads();
-                read_frags(buf ^ 1, 0, 0);
-            }
-            mfma_q(q & 1);
-            // the LDS writes and the global loads of this iteration must be issued within the first MFMA group: left to
-            // itself the scheduler sinks the loads to the end of the iteration and the next one stalls on them
-            if (q == 0) __builtin_amdgcn_sched_barrier(0);
-        }
-        buf ^= 1;
-    }
-    for (; it < nchunks; ++it) {       // last two chunks: nothing left to load
-        const bool has_next = it + 1 < nchunks;
-        if (has_next) store_chunk(buf ^ 1);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (q + 1 < NQ) {
-                read_frags(buf, q + 1, (q + 1) & 1);
-            } else {
-                __syncthreads();
-                if (has_next) read_frags(buf ^ 1, 0, 0);
-            }
-            mfma_q(q & 1);
-        }
+    // One loop body for every chunk, the last ones included: past the end the pointers stop advancing (the last chunk is fetched again),
+    // the planes written and the fragments read belong to no chunk and are never multiplied — no tail variants, one register allocation.
+    for (int it = 0; it < nchunks; ++it) {
+        if (it + 3 < nchunks) advance_a();   // up here: its tap / segment branch must not cut a half in two
+        advance_b(it + 2 < nchunks ? BK : 0);
+        store_b(buf ^ 1, rb);
+        load_b(rb);
+        read_frags(buf, 1, 1);
+        mfma_q(0);
+        deal_hints<MF, VPM, NP * (TM + TN) + NP * PB, PB>();
+        __syncthreads();
+        read_frags(buf ^ 1, 0, 0);
+        store_a(buf, ra);
+        load_a(ra);
+        mfma_q(1);
+        deal_hints<MF, VPM, NP * (TM + TN) + NP * PA, PA>();
         buf ^= 1;
     }
 
@@ -330,7 +390,12 @@ hipError_t launch_conv_gemm_split(const ConvParams &p_in, int planes, hipStream_
     }
     if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000 || p.Ktot % 32 != 0 || (planes != 2 && planes != 3)) return hipErrorInvalidValue;
     dim3 block(256);
-    auto grid = [&](int bm, int bn) { return dim3((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, p.ngroups); };
+    const bool xcd = knobs().split_xcd > 0 && p.ngroups == 1 && p.zdiv == 0;
+    p.xcd_tiles = xcd ? knobs().split_xcd : 0;
+    auto grid = [&](int bm, int bn) {
+        const int mt = (p.M + bm - 1) / bm, nt = (p.N + bn - 1) / bn;
+        return xcd ? dim3(((mt * nt + 7) / 8) * 8) : dim3(mt, nt, p.ngroups);
+    };
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.ngroups;
     const bool big = tiles128 >= 200;
     if (planes == 2) {

@@ -48,6 +48,7 @@ struct ConvParams {
     const float *zero;   // >= 64 KB of zeros (filled by the launcher): where halo / padding operand pointers are parked
     int zdiv;
     long x_zs0, x_zs1, w_zs0, w_zs1, o_zs0, o_zs1, b_zs1, r_zs0, r_zs1;
+    int xcd_tiles;       // set by launch_conv_gemm_split (0 or the column-group width): 1-D grid, tiles dealt to the XCDs in blocks that share operands
 };
 
 // banded conv_gemm launch (conv_gemm.hip): rows [0, mt_big * 128) in 128 x 128 tiles = workgroups [0, first_small), the rows
@@ -171,6 +172,7 @@ hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long lon
 // ------------------------------------------------------------------------------------------------
 struct Knobs {
     bool conv_bands = true;     // TS_CONV_BANDS=0: big conv layers as one plain grid of 128 x 128 tiles
+    int split_xcd = 8;          // TS_SPLIT_XCD: column-group width of conv_gemm_split's XCD-aware tile order (0: plain 2-D tile grid)
     bool prof_log = false;      // TS_PROF_LOG=1: one stderr line per conv launch while ts_prof is enabled
     bool no_graph = false;      // TS_NO_GRAPH=1: PixelCNN launches go out eagerly
     int pix_defer_p = -1;       // TS_PIX_DEFER_P: -1 auto (<= 128 clips), 0 / 1 forced
