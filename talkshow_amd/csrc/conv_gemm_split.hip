@@ -24,6 +24,29 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;   // LDS-qualified: volatile accesses must not fall back to flat
 
+// erf for this kernel's GELU epilogue: the odd rational x P(x^2) / Q(x^2) on [-4, 4] (the single-precision form of Eigen / XLA), 12 fused
+// multiply-adds + one v_rcp_f32 against ~40 instructions of erff.  Relative error < 5e-7 against float64 erf — a thirtieth of what the three-product
+// split itself leaves (1.7e-5 on the output).  conv_gemm_f32 keeps libm's erff: there the epilogue hides under the other workgroup's MFMAs
+// (measured neutral, tools/experiments/README.md); here 64 erf per lane are as many VALU instructions as a third of a K = 768 tile's main loop,
+// and the kernel is bound by instruction issue.
+__device__ __forceinline__ float split_erff(float x) {
+    x = fminf(fmaxf(x, -4.0f), 4.0f);
+    const float x2 = x * x;
+    float p = -2.72614225801306e-10f;
+    p = fmaf(p, x2, 2.77068142495902e-08f);
+    p = fmaf(p, x2, -2.10102402082508e-06f);
+    p = fmaf(p, x2, -5.69250639462346e-05f);
+    p = fmaf(p, x2, -7.34990630326855e-04f);
+    p = fmaf(p, x2, -2.95459980854025e-03f);
+    p = fmaf(p, x2, -1.60960333262415e-02f);
+    float q = -1.45660718464996e-05f;
+    q = fmaf(q, x2, -2.13374055278905e-04f);
+    q = fmaf(q, x2, -1.68282697438203e-03f);
+    q = fmaf(q, x2, -7.37332916720468e-03f);
+    q = fmaf(q, x2, -1.42647390514189e-02f);
+    return (p * x) * __builtin_amdgcn_rcpf(q);
+}
+
 // Scheduling hints for one half of a chunk (see the main loop): behind each of the MF MFMAs its share of the VALU work, of the NDS LDS
 // operations and one of the NVM global loads.  sched_group_barrier wants literal arguments, hence the recursion.
 template <int MASK, int N>
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p
         if (gres && !p.res_after_act) v += rvv;
         if (p.act == 1) v = v >= 0.f ? v : v * 0.2f;
         else if (p.act == 2) v = v > 0.f ? v : 0.f;
-        else if (p.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        else if (p.act == 3) v = 0.5f * v * (1.0f + split_erff(v * 0.70710678118654752440f));
         if (gres && p.res_after_act) v += rvv;
         return v;
     };
