@@ -161,7 +161,9 @@ int ts_face_generate(ts_face *face, const float *wav_dev, int B, int N, int fram
 /* OPT-IN arithmetic plan of the generator's GEMMs (no counterpart in the reference, which runs fp32 throughout): 0 = fp32 MFMA,
  * the default and the path every parity claim is made on; 3 / 6 = split-bf16: each fp32 operand becomes 2 / 3 bf16 terms and a
  * product 3 / 6 exact bf16 products accumulated in fp32 (csrc/conv_gemm_split.hip; measured error vs the reference golden in
- * DESIGN.md).  The first feature convolution, attention, LayerNorms and soft-max stay fp32.  Never applies to the body path. */
+ * DESIGN.md).  The first feature convolution, attention, LayerNorms and soft-max stay fp32.  Never applies to the body path.
+ * The first selection of the 3-product plan also writes each layer's weights as bf16 plane images (one extra copy of the weights in HBM;
+ * synchronises the device once). */
 int ts_face_set_arith(ts_face *face, int bf16_products);
 
 /* ---- audio front-end on the device: get_mfcc_ta (data_utils/utils.py:148-231) = torchaudio Resample(sr_in -> sr_out)

@@ -64,8 +64,9 @@ __device__ __forceinline__ void deal_hints() {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NP>
+template <int BM, int BN, int WM, int WN, int NP, bool BPRE>
 __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p) {
+    static_assert(!BPRE || NP == 2, "plane images hold two planes");
     constexpr int BK = 32;
     constexpr int LDS_LD = 20;       // dwords per LDS row: 32 bf16 (16 dwords) + 4 of padding -> 80 B pitch, conflict-free for ds_read_b128
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -246,6 +247,12 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(const ConvParams p
         }
     };
     auto store_b = [&](int buf, const f32x4 (&r)[PB]) {
+        if constexpr (BPRE) {   // the weights arrive as plane images: the 16 bytes a thread fetched are 8 bf16 of ONE plane
+            const int pl = (tid & 7) >> 2, dw = (tid & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4 *>(&Bs[buf][pl][i * 32 + lrow][dw]) = r[i];
+            return;
+        }
         uint2 sp[NP];
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -421,13 +428,43 @@ hipError_t launch_conv_gemm_split(const ConvParams &p_in, int planes, hipStream_
     };
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.ngroups;
     const bool big = tiles128 >= 200;
-    if (planes == 2) {
-        if (big) hipLaunchKernelGGL((conv_gemm_split_kernel<128, 128, 64, 64, 2>), grid(128, 128), block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_split_kernel<64, 64, 32, 32, 2>), grid(64, 64), block, 0, stream, p);
+    if (planes == 2 && p.w_planes) {
+        if (big) hipLaunchKernelGGL((conv_gemm_split_kernel<128, 128, 64, 64, 2, true>), grid(128, 128), block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_split_kernel<64, 64, 32, 32, 2, true>), grid(64, 64), block, 0, stream, p);
+    } else if (planes == 2) {
+        if (big) hipLaunchKernelGGL((conv_gemm_split_kernel<128, 128, 64, 64, 2, false>), grid(128, 128), block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_split_kernel<64, 64, 32, 32, 2, false>), grid(64, 64), block, 0, stream, p);
     } else {
-        if (big) hipLaunchKernelGGL((conv_gemm_split_kernel<128, 128, 64, 64, 3>), grid(128, 128), block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_split_kernel<64, 64, 32, 32, 3>), grid(64, 64), block, 0, stream, p);
+        if (p.w_planes) return hipErrorInvalidValue;
+        if (big) hipLaunchKernelGGL((conv_gemm_split_kernel<128, 128, 64, 64, 3, false>), grid(128, 128), block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_split_kernel<64, 64, 32, 32, 3, false>), grid(64, 64), block, 0, stream, p);
     }
+    return hipGetLastError();
+}
+
+// one thread per 4 consecutive k of a row: the arithmetic of split4 (round to nearest even, exact remainder), written as the image a
+// BPRE kernel copies into its LDS planes
+__global__ __launch_bounds__(256) void split_weight_planes_kernel(const float *__restrict__ w, uint32_t *__restrict__ planes, long n4) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    const f32x4 x = reinterpret_cast<const f32x4 *>(w)[idx];
+    const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x[0], x[1]}, bf16x2));
+    const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x[2], x[3]}, bf16x2));
+    const float r0 = x[0] - __builtin_bit_cast(float, h01 << 16), r1 = x[1] - __builtin_bit_cast(float, h01 & 0xffff0000u);
+    const float r2 = x[2] - __builtin_bit_cast(float, h23 << 16), r3 = x[3] - __builtin_bit_cast(float, h23 & 0xffff0000u);
+    const uint32_t l01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+    const uint32_t l23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r2, r3}, bf16x2));
+    const long chunk = idx >> 3;      // 8 threads per chunk of 32 k (K % 32 == 0: chunks never straddle rows)
+    const int q = (int)(idx & 7);
+    uint32_t *o = planes + chunk * 32 + 2 * q;
+    *reinterpret_cast<uint2 *>(o) = uint2{h01, h23};
+    *reinterpret_cast<uint2 *>(o + 16) = uint2{l01, l23};
+}
+
+hipError_t launch_split_weight_planes(const float *w, float *planes, long rows, int K, hipStream_t stream) {
+    if (!w || !planes || rows < 1 || K < 32 || K % 32) return hipErrorInvalidValue;
+    const long n4 = rows * (long)K / 4;
+    hipLaunchKernelGGL(split_weight_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<uint32_t *>(planes), n4);
     return hipGetLastError();
 }
 

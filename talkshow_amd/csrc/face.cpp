@@ -49,7 +49,7 @@ int load_conv3(const StateDict &sd, const std::string &k, int cout, int cin, int
 
 // generic ConvParams for a packed layer: rows (b, t) with t < Lout, input row t*stride + d
 void params_for(const ConvLayer &L, const float *x, int ldx, int B, int Lin, int Lout, int stride, const float *res, int ldr,
-                float *out, int ldo, int col0, int nstore, int act, ConvParams *p) {
+                float *out, int ldo, int col0, int nstore, int act, ConvParams *p, bool planes_ok = false) {
     std::memset(p, 0, sizeof(*p));
     p->M = B * Lout;
     p->Lout = Lout;
@@ -65,6 +65,10 @@ void params_for(const ConvLayer &L, const float *x, int ldx, int B, int Lin, int
     ConvGroup &G = p->g[0];
     G.x = x;
     G.w = L.w.f();
+    if (planes_ok && L.wp.p) {   // x3 plan: the layer's weights as plane images (ts_face_set_arith)
+        G.w = L.wp.f();
+        p->w_planes = 1;
+    }
     G.bias = L.bias.f();
     G.res = res;
     G.out = out;
@@ -84,7 +88,7 @@ struct ts_face {
     int fc_k[6] = {3, 3, 3, 3, 2, 2};
     LNp fp_ln;
     ConvLayer fp_proj;
-    DevBuf pos_w, pos_b;
+    DevBuf pos_w, pos_b, pos_wp;
     int pos_npad = 128, pos_ktot = 0;
     LNp enc_ln;
     std::vector<std::unique_ptr<EncLayer>> layers;
@@ -235,6 +239,30 @@ int ts_face_set_arith(ts_face *f, int bf16_products) {
     if (!f) return fail("ts_face_set_arith: null argument");
     if (bf16_products != 0 && bf16_products != 3 && bf16_products != 6) return fail("ts_face_set_arith: 0 (fp32), 3 or 6 bf16 products");
     f->split_planes = bf16_products == 0 ? 0 : (bf16_products == 3 ? 2 : 3);
+    if (f->split_planes == 2 && !f->pos_wp.p) {
+        // weights are constants: their two bf16 planes are made once, here, in the layout conv_gemm_split copies into LDS, and only the
+        // activations are split per call (the plane images have the size and pitch of the fp32 matrices: + 1 x the weights of HBM)
+        TS_HIP(hipSetDevice(f->ctx->device));
+        std::vector<ConvLayer *> all;
+        for (auto &c : f->fc) all.push_back(&c);
+        all.push_back(&f->fp_proj);
+        for (auto &L : f->layers)
+            for (ConvLayer *c : {&L->qkv, &L->outp, &L->ff1, &L->ff2}) all.push_back(c);
+        all.push_back(&f->afm);
+        for (auto &c : f->fn) all.push_back(&c);
+        if (f->CIN != 256) all.push_back(&f->fn0res);
+        for (auto &d : f->dec)
+            for (auto &c : d) all.push_back(&c);
+        for (auto &c : f->fin) all.push_back(&c);
+        for (ConvLayer *c : all) {
+            if (!c->w.p || c->ktot % 32) continue;
+            TS_TRY(c->wp.ensure(c->w.bytes));
+            TS_HIP(launch_split_weight_planes(c->w.f(), c->wp.f(), (long)(c->w.bytes / sizeof(float) / c->ktot), c->ktot, nullptr));
+        }
+        TS_TRY(f->pos_wp.ensure(f->pos_w.bytes));
+        TS_HIP(launch_split_weight_planes(f->pos_w.f(), f->pos_wp.f(), (long)(f->pos_w.bytes / sizeof(float) / f->pos_ktot), f->pos_ktot, nullptr));
+        TS_HIP(hipStreamSynchronize(nullptr));
+    }
     return 0;
 }
 
@@ -281,7 +309,7 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
     ConvParams p;
     auto conv = [&](const ConvLayer &Ly, const float *x, int ldx, int Bc, int Lin, int Lout, int stride, const float *res,
                     int ldr, float *o, int ldo, int col0, int nstore, int act) -> int {
-        params_for(Ly, x, ldx, Bc, Lin, Lout, stride, res, ldr, o, ldo, col0, nstore, act, &p);
+        params_for(Ly, x, ldx, Bc, Lin, Lout, stride, res, ldr, o, ldo, col0, nstore, act, &p, f->split_planes == 2);
         return run_conv(ctx, p, f->split_planes ? 20 + f->split_planes : 0, s);
     };
     auto ln = [&](const float *x, int C, const LNp &q, const float *post, int relu, float *o) -> int {
@@ -333,6 +361,10 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
         ConvGroup &G = p.g[0];
         G.x = w.H.f();
         G.w = f->pos_w.f();
+        if (f->split_planes == 2 && f->pos_wp.p) {
+            G.w = f->pos_wp.f();
+            p.w_planes = 1;
+        }
         G.bias = f->pos_b.f();
         G.res = w.H.f();
         G.out = w.TMP.f();

@@ -208,6 +208,7 @@ struct ConvLayer {
     int ngroups = 1, nseg = 0;
     ConvSeg segs[2][4];
     DevBuf w, bias;   // [ngroups][npad][ktot], [ngroups][npad]
+    DevBuf wp;        // face generator, x3 plan only: w as bf16 plane images (launch_split_weight_planes)
     std::string name;
 };
 

@@ -48,6 +48,7 @@ struct ConvParams {
     const float *zero;   // >= 64 KB of zeros (filled by the launcher): where halo / padding operand pointers are parked
     int zdiv;
     long x_zs0, x_zs1, w_zs0, w_zs1, o_zs0, o_zs1, b_zs1, r_zs0, r_zs1;
+    int w_planes;        // conv_gemm_split, 2 planes only: the weights are plane images already (split_weight_planes): no split of B in the kernel
     int xcd_tiles;       // set by launch_conv_gemm_split (0 or the column-group width): 1-D grid, tiles dealt to the XCDs in blocks that share operands
 };
 
@@ -63,6 +64,10 @@ hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream);
 // the same convolution on the bf16 matrix cores with fp32 operands split into `planes` bf16 terms (2: three products, ~2^-16;
 // 3: six products, fp32 grade) — conv_gemm_split.hip; an opt-in plan for tolerance-only GEMMs (the face generator)
 hipError_t launch_conv_gemm_split(const ConvParams &p, int planes, hipStream_t stream);
+// Weights of a layer as the plane images conv_gemm_split builds in LDS — per row and chunk of 32 k: 16 dwords of bf16(x) pairs, then 16
+// dwords of bf16(x - bf16(x)) pairs; the same size and pitch as the fp32 matrix (rows x K floats, K % 32 == 0).  Done once per layer when
+// the x3 plan is selected: weights are constants, only the activations need splitting per call.
+hipError_t launch_split_weight_planes(const float *w, float *planes, long rows, int K, hipStream_t stream);
 double conv_gemm_flops(const ConvParams &p);
 
 // ------------------------------------------------------------------------------------------------
