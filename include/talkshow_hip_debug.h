@@ -30,6 +30,9 @@ int ts_debug_clock_sample(unsigned long long *dev_out, int n, int window_us, voi
  * layer is launched in two bands (more than one round of 512 resident workgroups, not a whole number of rounds), 0 for a plain grid,
  * -1 on a bad argument.  No reference counterpart. */
 int ts_debug_conv_bands(int M, int N, int groups, int *out4);
+/* Host-only: the tile {row tile, column tile} workgroup `bid` of conv_gemm_split's XCD-aware 1-D grid works on (MT x NT tiles, column groups of
+ * `gw`); 1 = out2 filled, 0 = that workgroup has no tile, -1 = bad argument. */
+int ts_debug_split_tile(int bid, int MT, int NT, int gw, int *out2);
 /* Host-only helper (no GPU needed): the TILED copy of a row-major weight matrix W[N][ldw] (K columns used) that the
  * PixelCNN chain kernel multiplies with — every 16-column x 16-k operand fragment one contiguous KB in lane order
  * (DESIGN.md §3/§4); epi 0 = linear column order, 1 = gate (8 tanh channels + their 8 sigmoid partners per tile,

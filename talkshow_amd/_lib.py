@@ -33,6 +33,7 @@ SIGNATURES = {
     "ts_debug_skinny_trace": (_i, [C.POINTER(C.c_uint64), _i]),
     "ts_debug_clock_sample": (_i, [_vp, _i, _i, _vp]),
     "ts_debug_conv_bands": (_i, [_i, _i, _i, C.POINTER(_i)]),
+    "ts_debug_split_tile": (_i, [_i, _i, _i, _i, C.POINTER(_i)]),
     "ts_debug_tile_weights": (_i, [_vp, _i, _i, C.c_long, _i, _i, _vp]),
     "ts_assemble_full": (_i, [_vp, _vp, _i, _vp, _i, _i, _fp, _vp, _vp]),
     "ts_stream_destroy": (_i, [_vp, _vp]),

@@ -105,6 +105,12 @@ int ts_debug_conv_bands(int M, int N, int groups, int *out4) {
     out4[0] = bd.mt_big; out4[1] = bd.mt_small; out4[2] = bd.first_small; out4[3] = bd.total;
     return banded ? 1 : 0;
 }
+// Host-only (no GPU): tile (out2 = {row tile, column tile}) that workgroup `bid` of conv_gemm_split's 1-D grid works on for an MT x NT
+// tile grid and column groups of `gw` tiles; returns 1, 0 if that workgroup has no tile, -1 on a bad argument
+int ts_debug_split_tile(int bid, int MT, int NT, int gw, int *out2) {
+    if (bid < 0 || MT < 1 || NT < 1 || gw < 1 || !out2) return fail("ts_debug_split_tile: bad argument") ? -1 : -1;
+    return ts::split_tile_of(bid, MT, NT, gw, out2[0], out2[1]) ? 1 : 0;
+}
 int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int gateD, float *out) {
     if (!W || !out || N < 1 || K < 16 || K % 16 || ldw < K) return fail("ts_debug_tile_weights: bad argument");
     if (epi == ts::EPI_GATE && (gateD < 8 || gateD % 8 || N % (2 * gateD))) return fail("ts_debug_tile_weights: gate tiles need gateD % 8 == 0 and N % (2 gateD) == 0");

@@ -64,6 +64,25 @@ hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream);
 // the same convolution on the bf16 matrix cores with fp32 operands split into `planes` bf16 terms (2: three products, ~2^-16;
 // 3: six products, fp32 grade) — conv_gemm_split.hip; an opt-in plan for tolerance-only GEMMs (the face generator)
 hipError_t launch_conv_gemm_split(const ConvParams &p, int planes, hipStream_t stream);
+// conv_gemm_split's XCD-aware tile order (one definition for the kernel and for the host-side test): workgroup `bid` of a 1-D grid of
+// 8 ceil(MT NT / 8) -> tile (tx, ty) of an MT x NT tile grid, false if the workgroup has no tile.  Workgroup ids go round-robin over the 8
+// XCDs; XCD x takes the x-th contiguous eighth of a tile list that runs through column groups of GW tiles, rows inside a group, columns fastest.
+__host__ __device__ inline bool split_tile_of(int bid, int MT, int NT, int GW, int &tx, int &ty) {
+    const int total = MT * NT, per = (total + 7) >> 3;
+    const int L = (bid & 7) * per + (bid >> 3);
+    if (L >= total) return false;
+    const int full = NT / GW;
+    int g = L / (MT * GW), r = L - g * MT * GW, gn = GW;
+    if (g >= full) {   // the last, narrower column group
+        g = full;
+        r = L - full * MT * GW;
+        gn = NT - GW * full;
+    }
+    tx = r / gn;
+    ty = g * GW + (r - tx * gn);
+    return true;
+}
+
 // Weights of a layer as the plane images conv_gemm_split builds in LDS — per row and chunk of 32 k: 16 dwords of bf16(x) pairs, then 16
 // dwords of bf16(x - bf16(x)) pairs; the same size and pitch as the fp32 matrix (rows x K floats, K % 32 == 0).  Done once per layer when
 // the x3 plan is selected: weights are constants, only the activations need splitting per call.

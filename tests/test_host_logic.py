@@ -245,6 +245,36 @@ def test_conv_band_plan_covers_every_row_once():
     assert lib.ts_debug_conv_bands(0, 64, 1, out) == -1
 
 
+def test_split_gemm_tile_order_covers_every_tile_once():
+    """`conv_gemm_split` (the opt-in bf16x3 face plan) runs on a 1-D grid whose workgroups pick their tile through `split_tile_of`
+    (`csrc/kernels.h`, the same function on the device and here): ids go round-robin over the 8 XCDs, XCD x takes the x-th eighth of a
+    tile list ordered by column groups.  Host logic, no GPU: every tile exactly once, padding workgroups get none, and the 64 workgroups
+    an XCD holds at a time (64 consecutive list positions) touch few distinct row and column tiles — that is the point of the order."""
+    import ctypes as C
+    from talkshow_amd import _lib
+    lib = _lib.load()
+    out = (C.c_int * 2)()
+    for MT, NT, gw in ((150, 6, 8), (150, 18, 8), (150, 24, 8), (8000, 4, 8), (2, 1, 8), (37, 11, 4), (5, 5, 8), (150, 24, 6)):
+        total, per = MT * NT, -(-MT * NT // 8)
+        seen, by_xcd = set(), {x: [] for x in range(8)}
+        for bid in range(per * 8):
+            r = lib.ts_debug_split_tile(bid, MT, NT, gw, out)
+            assert r in (0, 1)
+            if r:
+                t = (out[0], out[1])
+                assert 0 <= t[0] < MT and 0 <= t[1] < NT and t not in seen
+                seen.add(t)
+                by_xcd[bid & 7].append(t)
+        assert len(seen) == total                                   # a bijection onto the tile grid
+        assert lib.ts_debug_split_tile(per * 8 - 1, MT, NT, gw, out) == (1 if total % 8 == 0 else 0)
+        if total >= 8 * 64:
+            for x, tiles in by_xcd.items():                          # what one XCD holds at a time shares operands:
+                for a in range(0, len(tiles) - 63, 64):               # 64 tiles out of a compact block (a plain grid order: ~150 x 4)
+                    rows, cols = {t[0] for t in tiles[a:a + 64]}, {t[1] for t in tiles[a:a + 64]}
+                    assert len(rows) * len(cols) <= 256 and len(cols) <= 2 * gw, (MT, NT, gw, x, a, len(rows), len(cols))
+    assert lib.ts_debug_split_tile(0, 0, 4, 8, out) == -1
+
+
 def test_bench_pass_plan():
     """bench.py groups the queued 32-clip steps into chain passes: full passes of G batches, then the remainder — the
     driver's `--steps 20` at G = 8 is 8 + 8 + 4, every step is run exactly once."""
