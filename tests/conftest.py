@@ -1,6 +1,13 @@
 import os
 import sys
 
+# The CPU suite is BLAS-heavy (the oracle's full-grid PixelCNN recompute).  On an 8-core box OpenBLAS and torch's OpenMP pool default
+# to 8 threads EACH; 4 run the suite in the same wall time at half the CPU time (measured: 32 s / 1 m 51 s of CPU against 32 s / 3 m 26 s for
+# the two heaviest tests) and keep it from degrading by an order of magnitude when the host's cores are contended.  Override by
+# exporting the variables.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
+
 import numpy as np
 import pytest
 
@@ -11,6 +18,11 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
 def pytest_configure(config):
+    try:   # numpy may have been imported (by a plugin) before the variables above were set
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(int(os.environ["OPENBLAS_NUM_THREADS"]))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
     config.addinivalue_line("markers", "slow: tens of seconds on CPU")
 
