@@ -9,8 +9,11 @@
 // Products of bf16 values are exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32 at 16x the rate of the fp32
 // MFMA, so the matrix pipe needs 3/16 or 6/16 of conv_gemm_f32's time.  tools/split_bf16_study.py (CPU emulation on the
 // reference golden clip): NP = 2 -> hidden state within 7e-5, output within 2e-5 of the reference; NP = 3 -> 4e-6 / 1e-6.
-// Operands stay fp32 in HBM: the split happens between the global-load registers and the LDS planes (v_cvt_pk_bf16_f32 +
-// one subtraction per extra plane), so layers need not agree on a plan.  Same segments / taps / epilogue as conv_gemm_f32.
+// Activations stay fp32 in HBM: the split happens between the global-load registers and the LDS planes (v_cvt_pk_bf16_f32 +
+// one subtraction per extra plane), so layers need not agree on a plan.  Weights are constants: for the 3-product plan they are split
+// once, when the plan is selected, into plane images this kernel copies into LDS (BPRE, launch_split_weight_planes at the end of the
+// file).  Same segments / taps as conv_gemm_f32; its own tile order (split_tile_of, kernels.h) and GELU (split_erff) — round 4's
+// counters on this kernel and what each step bought are in profiles/r04_notes/split_bound.txt.
 #include "kernels.h"
 #include <cstdint>
 
