@@ -39,6 +39,21 @@ def golden():
     return load
 
 
+def assert_close_measured(name, got, ref, atol):
+    """assert_allclose(atol, rtol=0) that also records what it measured: prints `name: max |err|` (visible with -s or on failure)
+    and, when TS_MEASURED_LOG names a file, appends one JSON line to it — the bounds written in the tests are 2x those records."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    err = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) if got.size else 0.0
+    print(f"\n[measured] {name}: max |err| = {err:.3e} (bound {atol:.1e})")
+    log = os.environ.get("TS_MEASURED_LOG")
+    if log:
+        import json
+        with open(log, "a") as f:
+            f.write(json.dumps({"name": name, "max_abs_err": err, "bound": atol}) + "\n")
+    assert got.shape == ref.shape, f"{name}: shape {got.shape} vs {ref.shape}"
+    assert err <= atol, f"{name}: max |err| {err:.3e} > {atol:.1e}"
+
+
 def has_gpu():
     try:
         import torch

@@ -10,9 +10,11 @@
   re-derived from the device's own logits with the oracle's inverse CDF (exact: the sampler's exponential is fp32 mul / add only),
   and a chi-square of 204 800 Philox draws against the softmax of a real 2 048-logit row.
 
-Counting rule for index outputs compared with the CPU reference: a decision whose reference top-2 margin is below NEAR_TIE may
-legitimately flip under a different fp32 summation order; everything else must be equal.  The tests print
-`equal / total` so the count can be quoted.
+Counting rule for index outputs compared with the CPU reference: EQUALITY.  The kernels are deterministic and the goldens are
+fixed, and this build reproduces every one of the 2 x 4 800 decisions, so the tests assert `equal == total` (north_star:
+"bit-exact for predicted code indices under greedy decode").  The reference's top-2 margins ride along in the goldens and are
+only used to word the failure message (a difference at a margin below NEAR_TIE is a summation-order flip, anything else a bug);
+they are not an allowance.  `__graft_entry__.smoke()` prints the same counts so that the driver's record carries them.
 """
 import argparse
 import json
@@ -99,8 +101,9 @@ def test_vq_encode_b32_golden_counts(hip, golden):
     diff = got32 != ref
     print(f"\nvq_encode_b32: codes equal to the reference {int((~diff).sum())} / {diff.size}"
           + (f"; margins at the differences {np.sort(margin[diff])[:5]}" if diff.any() else ""))
-    assert (margin[diff] < NEAR_TIE_DIST).all(), f"a decision with margin {margin[diff].max():.2e} differs from the reference"
-    assert diff.sum() <= 4
+    assert not diff.any(), (f"{int(diff.sum())} of {diff.size} nearest-neighbour decisions differ from the reference's VQVAE.encode; "
+                            f"reference distance margins there: {np.sort(margin[diff])[:8]} "
+                            f"({'all' if (margin[diff] < NEAR_TIE_DIST).all() else 'NOT all'} under the near-tie bound {NEAR_TIE_DIST})")
     # the reference's reconstruction of clips 0 and 1 (VQVAE.decode of the reference codes)
     for k in range(2):
         if not diff[k].any():
@@ -125,8 +128,8 @@ def _body_wrapper(tmp_path):
 def test_greedy_b32_golden_counts(hip, golden, tmp_path):
     """32 clips x 75 x 2 = 4 800 greedy decisions of the reference harness (`body_e2e_b32`: reference `GatedPixelCNN.forward`
     driven position by position over the whole batch) against one BASELINE batch and against the same clips inside the bench's
-    256-clip pass (wide kernel).  Decoding is autoregressive, so a clip is compared up to its first difference, which must sit
-    on a reference near-tie; poses of the stored clips within 1e-4."""
+    256-clip pass (wide kernel).  Every code must be equal; a failure reports, per clip, the first divergence and the
+    reference's top-2 margin there.  Poses of the stored clips within 1e-4."""
     _lib = hip[0]
     g = golden("body_e2e_b32")
     seed, B, T = (int(v) for v in g["mfcc_seed"])
@@ -140,24 +143,24 @@ def test_greedy_b32_golden_counts(hip, golden, tmp_path):
     c32, c256 = c32.cpu().numpy(), c256.cpu().numpy()[160:192]
     np.testing.assert_array_equal(c256, c32)
     np.testing.assert_array_equal(p256[160:192].cpu().numpy(), p32.cpu().numpy())
-    equal = 0
+    equal, report = 0, []
     for b in range(B):
         d = np.flatnonzero((c32[b] != ref[b]).reshape(-1))
         if d.size == 0:
             equal += ref[b].size
             continue
         first = d[0]
-        equal += first
+        equal += first                                                   # autoregressive: a clip counts up to its first difference
         m = margin[b].reshape(-1)[first]
-        print(f"\nclip {b}: first difference at position {first}, reference top-2 margin {m:.2e}")
-        assert m < NEAR_TIE_LOGIT, f"clip {b} leaves the reference at a decision with margin {m:.2e}"
+        report.append(f"clip {b}: first difference at position {first}, reference top-2 margin {m:.2e}"
+                      f" ({'near-tie' if m < NEAR_TIE_LOGIT else 'NOT a near-tie'})")
     print(f"\nbody_e2e_b32: greedy codes equal to the reference {equal} / {ref.size} (margins: min {margin.min():.2e}, "
           f"{int((margin < NEAR_TIE_LOGIT).sum())} under {NEAR_TIE_LOGIT})")
-    assert equal >= ref.size - 300                                       # at most two clips may leave at a near-tie
+    assert equal == ref.size, f"greedy codes equal to the reference {equal} / {ref.size}: " + "; ".join(report)
     p32 = p32.cpu().numpy()
-    for k, b in enumerate(g["pose_clips"]):
-        if np.array_equal(c32[b], ref[b]):
-            np.testing.assert_allclose(p32[b], g["poses"][k], atol=1e-4, rtol=0)
+    err = max(float(np.abs(p32[b] - g["poses"][k]).max()) for k, b in enumerate(g["pose_clips"]))
+    print(f"body_e2e_b32: max |pose err| over the stored clips {err:.2e}")
+    assert err <= 1e-4
 
 
 def test_full_size_sampling_vs_oracle(hip, golden):

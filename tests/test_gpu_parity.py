@@ -13,10 +13,16 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import assert_close_measured
 from oracle import talkshow_oracle as O
 from talkshow_amd import synth
 
 pytestmark = pytest.mark.gpu
+
+# PixelCNN logits (|logit| ~ 9-30) against the reference's: the bound is 2x the largest error MEASURED on the MI355X over every
+# logits comparison of this file (profiles/r05_notes/measured_errors.jsonl); the smallest top-2 margin that decides a code in the
+# batch-32 golden is 3.4e-4, so the bound must stay well under it.
+LOGIT_ATOL = 3e-4
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -285,10 +291,10 @@ def test_pixelcnn_golden(hip, golden, name):
     m = _pix_module(g["cfg"])
     # 1. teacher forced: logits of every position, no error propagation (GatedPixelCNN.forward)
     _, logits = m.run(g["label"], g["aud"], mode=_lib.TS_TEACHER_FORCED, codes=g["codes"], want_logits=True)
-    np.testing.assert_allclose(logits.cpu().numpy(), g["full_logits"], atol=3e-4, rtol=0)
+    assert_close_measured(f"{name}.teacher_forced_logits", logits.cpu().numpy(), g["full_logits"], LOGIT_ATOL)
     # 2. free-running greedy decode: bit-exact code indices
     codes, step_logits = m.run(g["label"], g["aud"], mode=_lib.TS_SAMPLE_GREEDY, want_logits=True)
-    np.testing.assert_allclose(step_logits.cpu().numpy(), g["step_logits"], atol=3e-4, rtol=0)
+    assert_close_measured(f"{name}.step_logits", step_logits.cpu().numpy(), g["step_logits"], LOGIT_ATOL)
     np.testing.assert_array_equal(codes.cpu().numpy(), g["codes"])
     # 3. reference call shape of forward: (B,H,2) codes, (B,256,H,2) audio -> (B,V,H,2)
     aud4 = torch.from_numpy(g["aud"]).cuda().transpose(1, 2).unsqueeze(-1).repeat(1, 1, 1, 2)
@@ -313,9 +319,9 @@ def test_pixelcnn_constructor_variants(hip, golden, tag, audio, bh):
     B, H, W = ref.shape
     aud = g["aud"] if audio else None
     _, logits = m.run(g["label"], aud, mode=_lib.TS_TEACHER_FORCED, codes=ref, want_logits=True, shape=(B, H, W))
-    np.testing.assert_allclose(logits.cpu().numpy(), g[tag + "_full_logits"], atol=3e-4, rtol=0)
+    assert_close_measured(f"pix_variants.{tag}.teacher_forced_logits", logits.cpu().numpy(), g[tag + "_full_logits"], LOGIT_ATOL)
     codes, step = m.run(g["label"], aud, mode=_lib.TS_SAMPLE_GREEDY, want_logits=True, shape=(B, H, W))
-    np.testing.assert_allclose(step.cpu().numpy(), g[tag + "_step_logits"], atol=3e-4, rtol=0)
+    assert_close_measured(f"pix_variants.{tag}.step_logits", step.cpu().numpy(), g[tag + "_step_logits"], LOGIT_ATOL)
     np.testing.assert_array_equal(codes.cpu().numpy(), ref)
     # reference call shapes: forward(x, label[, aud (B,256,H,W)]) -> (B,V,H,W); generate(label, shape, batch_size[, aud_feat])
     aud4 = torch.from_numpy(g["aud"]).cuda().transpose(1, 2).unsqueeze(-1).repeat(1, 1, 1, W) if audio else None
@@ -815,6 +821,41 @@ def test_face_split_bf16_plan_vs_reference_golden(hip, golden, products, tol_hid
     assert torch.equal(again, base)
 
 
+def test_face_split_bf16_plan_at_baseline_shapes(hip, golden):
+    """The OPT-IN bf16x3 plan where configs[2] runs it: the two reference-golden 10 s clips inside a batch of 64 (output against the
+    reference golden, hidden state against the pinned oracle's `wav2vec2_forward`: the 10 s golden holds no hidden state), and the
+    60 s clip of `test_face_one_minute_clip_vs_oracle` (attention over 1 800 frames).  Same 1e-4 bar as the fp32 plan; the measured
+    errors are recorded (TS_MEASURED_LOG)."""
+    from oracle import face_oracle as FO
+    from talkshow_amd.modules import FaceGenerator
+    g = golden("face_10s")
+    seed, B0, N = [int(v) for v in g["wav_seed"]]
+    gw = synth.wav16(seed, B0, N)
+    sd = synth.face_state_dict(seed=7)
+    m = FaceGenerator().cuda()
+    m.load_state_dict(synth.to_torch(sd))
+    B, slots = 64, (5, 63)
+    wav = synth.wav16(500, B, N)
+    ids = np.eye(4, dtype=np.float32)[np.arange(B) % 4]
+    for k, s_ in enumerate(slots):
+        wav[s_], ids[s_] = gw[k], g["ids"][k]
+    out, hid = m.set_arith(3).run(wav, ids, 300, want_hidden=True)
+    out, hid = out.cpu().numpy(), hid.cpu().numpy()
+    ref_h = FO.wav2vec2_forward(gw, sd, 300)
+    for k, s_ in enumerate(slots):
+        assert_close_measured(f"face_bf16x3.10s_in_b64.out[{k}]", out[s_], g["out"][k], 1e-4)
+        assert_close_measured(f"face_bf16x3.10s_in_b64.hidden[{k}]", hid[s_], ref_h[k], 1e-4)
+    sd5 = synth.face_state_dict(seed=5)
+    m5 = FaceGenerator().cuda()
+    m5.load_state_dict(synth.to_torch(sd5))
+    N, frames = 16000 * 60, 30 * 60
+    wav = synth.wav16(43 + 60, 1, N)
+    ids = np.eye(4, dtype=np.float32)[[2]]
+    out, hid = m5.set_arith(3).run(wav, ids, frames, want_hidden=True)
+    assert_close_measured("face_bf16x3.60s.out", out.cpu().numpy(), FO.face_generator(wav, ids, sd5, frames), 1e-4)
+    assert_close_measured("face_bf16x3.60s.hidden", hid.cpu().numpy(), FO.wav2vec2_forward(wav, sd5, frames), 1e-4)
+
+
 def test_face_one_minute_clip_vs_oracle(hip):
     """A 60 s clip in ONE call (960 000 samples -> 1 800 frames: attention rows of 1 824 entries, beyond the 512 the softmax
     kernel keeps in registers) against the CPU oracle — the reference's `infer_on_audio` takes a wav of any length
@@ -899,7 +940,7 @@ def test_single_layer_pixelcnn(hip):
     label = synth.speaker_ids(2)
     codes, logits = px.run(label, aud, mode=_lib.TS_SAMPLE_GREEDY, want_logits=True)
     ref, rl = O.pixelcnn_generate(label, np.repeat(aud.transpose(0, 2, 1)[:, :, :, None], 2, axis=3), sd, 1, 5, return_logits=True)
-    np.testing.assert_allclose(logits.cpu().numpy(), rl, atol=3e-4, rtol=0)
+    assert_close_measured("single_layer.step_logits", logits.cpu().numpy(), rl, LOGIT_ATOL)
     np.testing.assert_array_equal(codes.cpu().numpy(), ref)
 
 
