@@ -20,14 +20,10 @@
 //     double-buffered in registers (see the comment at the main loop for how the non-MFMA instruction count is kept low).
 //   * convolution taps / stride / transposed-conv phases are "segments": (row shift, channel range) pairs, so only
 //     valid taps are multiplied (no zero-insertion for ConvTranspose, no wasted taps for stride 2).
-#include "kernels.h"
+#include "conv_tile.h"
 #include <cstdlib>
 
 namespace ts {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) f32x4 lds_f32x4;   // LDS-qualified: volatile accesses must not fall back to flat
 
 // one BM x BN output tile at (m0, n0) of problem / group `zidx`; smem: 2 * (BM + BN) * (BK + 4) floats of LDS
 template <int BM, int BN, int WM, int WN, int BK = 32>
@@ -43,16 +39,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const int zidx, c
     float (*Bs)[BN][LDS_LD] = reinterpret_cast<float (*)[BN][LDS_LD]>(smem + 2 * BM * LDS_LD);
 
     const ConvGroup &g = p.g[p.zdiv > 0 ? 0 : zidx];
-    const float *gx = g.x, *gw = g.w, *gbias = g.bias, *gres = g.res;
-    float *gout = g.out;
-    if (p.zdiv > 0) {   // batched problems: shift every pointer by this problem's offsets
-        const int z0 = zidx / p.zdiv, z1 = zidx - z0 * p.zdiv;
-        gx += z0 * p.x_zs0 + z1 * p.x_zs1;
-        gw += z0 * p.w_zs0 + z1 * p.w_zs1;
-        gout += z0 * p.o_zs0 + z1 * p.o_zs1;
-        if (gbias) gbias += z1 * p.b_zs1;
-        if (gres) gres += z0 * p.r_zs0 + z1 * p.r_zs1;
-    }
+    const ConvTilePtrs tp = conv_tile_ptrs(p, g, zidx);
+    const float *gx = tp.x, *gw = tp.w;
     const long ldw = p.ldw > 0 ? p.ldw : p.Ktot;
     const int w_rows = p.w_rows > 0 ? p.w_rows : 0x7fffffff;
     const int tid = threadIdx.x;
@@ -287,68 +275,14 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const int zidx, c
         buf ^= 1;
     }
 
-    // ---- epilogue: bias (+ residual) + activation, masked store ----
-    // The MFMA operands are swapped (weights as A, activations as B: the same products in the same k order, the same bits), so an
-    // accumulator block holds D[channel][row]: lane (li, lh) owns output row m = li and, per group g of 4 registers, the 4
-    // CONSECUTIVE channels 8 g + 4 lh .. + 3 — bias, residual and output move as 16-byte vectors (4 stores per 32 x 32 block
-    // instead of 16; the residual values of a block are fetched together, ahead of their use).  Rows / buffers that are not
-    // 16-byte aligned (the 39- / 90- / 129-wide pose rows) and channel tails take the scalar form.
-    const bool vec_out = ((p.ldo | g.out_col0) & 3) == 0 && (reinterpret_cast<uintptr_t>(gout) & 15) == 0;
-    const bool vec_res = gres && (p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(gres) & 15) == 0;
-    const bool vec_bias = gbias && (reinterpret_cast<uintptr_t>(gbias) & 15) == 0;
-    auto activate = [&](float v, float rvv) {
-        if (gres && !p.res_after_act) v += rvv;
-        if (p.act == 1) v = v >= 0.f ? v : v * 0.2f;
-        else if (p.act == 2) v = v > 0.f ? v : 0.f;
-        else if (p.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-        if (gres && p.res_after_act) v += rvv;
-        return v;
-    };
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WM + i * 32 + li;
-        const bool mok = m < p.M;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nb0 = n0 + wn * WN + j * 32 + 4 * lh;
-            f32x4 rv[4], bv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nb = nb0 + 8 * q;
-                const bool full = nb + 3 < p.N;
-                bv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (gbias) {
-                    if (vec_bias && full) bv[q] = *reinterpret_cast<const f32x4 *>(gbias + nb);
-                    else
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) bv[q][r] = nb + r < p.N ? gbias[nb + r] : 0.f;
-                }
-                rv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (gres && mok) {
-                    const float *rp = gres + (long)m * p.ldr + nb;
-                    if (vec_res && full) rv[q] = *reinterpret_cast<const f32x4 *>(rp);
-                    else
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) rv[q][r] = nb + r < p.N ? rp[r] : 0.f;
-                }
-            }
-            if (mok) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int nb = nb0 + 8 * q;
-                    f32x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = activate(acc[i][j][4 * q + r] + bv[q][r], rv[q][r]);
-                    float *op = gout + (long)m * p.ldo + g.out_col0 + nb;
-                    if (vec_out && nb + 3 < p.N) *reinterpret_cast<f32x4 *>(op) = v;
-                    else
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (nb + r < p.N) op[r] = v[r];
-                }
-            }
+    // the last chunk's barrier sits behind everybody's last fragment read: the operand tiles are free to become the epilogue's slabs
+    if constexpr ((TN == 1 || TN == 2 || TN == 4) && 4 * 32 * WN <= 2 * (BM + BN) * LDS_LD) {
+        if (!p.epi_regs && conv_tile_staged_ok(p, g, tp)) {   // wave-uniform
+            conv_tile_epilogue_staged<TM, TN>(p, g, tp, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (32 * WN));
+            return;
         }
     }
+    conv_tile_epilogue<TM, TN>(p, g, tp, acc, m0 + wm * WM, n0 + wn * WN, li, lh);   // conv_tile.h
 }
 
 template <int BM, int BN, int WM, int WN, int BK = 32>
@@ -422,10 +356,18 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) p.zero = skinny_zero_buffer(dev);
     }
+    p.epi_regs = knobs().conv_staged ? 0 : 1;
+    if (tile >= 100) {   // tuning / tests: tile id + 100 = the same tile with the register epilogue
+        p.epi_regs = 1;
+        tile -= 100;
+    }
     dim3 block(256);
     auto grid = [&](int bm, int bn) { return dim3((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, p.ngroups); };
     // zero buffer (ts::skinny_init, called by ts_ctx_create): 64 Ki floats; parked pointers walk at most Ktot floats of it
     if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000) return hipErrorInvalidValue;
+    if (tile >= 31 && tile <= 49) return launch_conv_gemm_ring(p, tile - 30, stream);   // LDS-DMA ring engine (conv_gemm_ring.hip)
+    if (tile == 0 && knobs().conv_ring > 0 && pick_tile(p) == 1 && launch_conv_gemm_ring(p, knobs().conv_ring, stream) == hipSuccess)
+        return hipSuccess;   // (a layer the ring engine does not take — segments that are not multiples of its stage depth — falls through)
     if (tile == 0 && pick_tile(p) == 1) {
         const bool banded = knobs().conv_bands;   // TS_CONV_BANDS=0: plain grid (A/B, tests)
         ConvBands bd;

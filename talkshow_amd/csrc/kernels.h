@@ -49,6 +49,7 @@ struct ConvParams {
     int zdiv;
     long x_zs0, x_zs1, w_zs0, w_zs1, o_zs0, o_zs1, b_zs1, r_zs0, r_zs1;
     int w_planes;        // conv_gemm_split, 2 planes only: the weights are plane images already (split_weight_planes): no split of B in the kernel
+    int epi_regs;        // set by the launchers (TS_CONV_STAGED=0): epilogue straight from the accumulator registers instead of the coalesced, LDS-staged form
     int xcd_tiles;       // set by launch_conv_gemm_split (0 or the column-group width): 1-D grid, tiles dealt to the XCDs in blocks that share operands
 };
 
@@ -186,6 +187,8 @@ hipError_t launch_assemble_full(const float *body, const float *face, const floa
                                 float *out, hipStream_t stream);
 // int64 -> int32 (labels, teacher-forced codes)
 hipError_t launch_i64_to_i32(const int64_t *src, int *dst, long n, hipStream_t stream);
+// dst[0..2] = a, b, c, carried by the launch's own arguments (no host buffer has to outlive the call)
+hipError_t launch_set_words3(uint64_t *dst, uint64_t a, uint64_t b, uint64_t c, hipStream_t stream);
 // measurement aid: n records of (wall ticks since start, wall ticks of the window, shader cycles of the window), 100 MHz wall clock
 hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long long window_ticks, hipStream_t stream);
 
@@ -196,6 +199,8 @@ hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long lon
 // ------------------------------------------------------------------------------------------------
 struct Knobs {
     bool conv_bands = true;     // TS_CONV_BANDS=0: big conv layers as one plain grid of 128 x 128 tiles
+    bool conv_staged = true;    // TS_CONV_STAGED=0: conv_gemm_f32 stores from the accumulator registers (32 rows x 32 B per instruction) instead of whole rows through LDS
+    int conv_ring = 0;          // TS_CONV_RING=<variant>: layers that take 128 x 128 tiles run on the LDS-DMA ring engine (conv_gemm_ring.hip)
     int split_xcd = 8;          // TS_SPLIT_XCD: column-group width of conv_gemm_split's XCD-aware tile order (0: plain 2-D tile grid)
     bool prof_log = false;      // TS_PROF_LOG=1: one stderr line per conv launch while ts_prof is enabled
     bool no_graph = false;      // TS_NO_GRAPH=1: PixelCNN launches go out eagerly

@@ -81,9 +81,7 @@ struct ts_pixelcnn {
         DevBuf aud_all, AE, AEV, AEH, AEH1, AV1C, AV1P, tok32, CR, XV, OV0, OVlast, HV, V2H, P, Q1, Q0, XH, G, T0, Y, LG, tfcodes;
         // every pointer inside the captured kernels is one of the buffers above or the staging buffers below, so a graph
         // is valid for any caller pointers; key = (B, H, H0, mode)
-        DevBuf codes_int, unif_int, dyn;
-        uint64_t dyn_host[16][3] = {};   // ring of sources for the async H2D copy of {seed, clip0, position base}: must outlive the call
-        unsigned dyn_slot = 0;
+        DevBuf codes_int, unif_int, dyn;   // dyn: {seed, clip0, position base} of the call being replayed, written by a kernel ahead of it
         hipStream_t cap_stream = nullptr;
         std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
         std::map<std::tuple<int, int, int, int>, std::pair<long, double>> graph_stats;   // skinny launches, flops
@@ -877,12 +875,9 @@ int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const
     c.dyn = static_cast<const uint64_t *>(w->dyn.p);
     if (c.mode == TS_SAMPLE_UNIFORMS)
         TS_HIP(hipMemcpyAsync(w->unif_int.p, uniforms, (size_t)c.B * c.H * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    // the host source of the async copy must stay intact until the copy has executed: a ring of 16 slots per Work
-    uint64_t *dh = w->dyn_host[w->dyn_slot++ & 15];
-    dh[0] = c.seed;
-    dh[1] = (uint64_t)c.clip0;
-    dh[2] = (uint64_t)c.pos_base;
-    TS_HIP(hipMemcpyAsync(w->dyn.p, dh, 3 * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    // the call's sampler words travel as the ARGUMENTS of a one-thread launch (copied when the launch is queued): no host buffer
+    // has to stay intact behind the call, so any number of calls may be queued on the stream without a synchronisation
+    TS_HIP(launch_set_words3(static_cast<uint64_t *>(w->dyn.p), c.seed, (uint64_t)c.clip0, (uint64_t)c.pos_base, s));
     auto it = w->graphs.find(key);
     if (it == w->graphs.end()) {
         if (!w->cap_stream) TS_HIP(hipStreamCreateWithFlags(&w->cap_stream, hipStreamNonBlocking));

@@ -221,6 +221,19 @@ hipError_t launch_i64_to_i32(const int64_t *src, int *dst, long n, hipStream_t s
     return hipGetLastError();
 }
 
+// three 64-bit words (the sampler's {seed, first clip index, Philox position base}) written by a kernel whose ARGUMENTS carry
+// them: arguments are copied when the launch is queued, so — unlike an asynchronous copy out of host memory — nothing on the
+// host has to outlive the call, however many calls are queued behind each other on the stream
+__global__ void set_words3_kernel(uint64_t *dst, uint64_t a, uint64_t b, uint64_t c) {
+    dst[0] = a;
+    dst[1] = b;
+    dst[2] = c;
+}
+hipError_t launch_set_words3(uint64_t *dst, uint64_t a, uint64_t b, uint64_t c, hipStream_t stream) {
+    hipLaunchKernelGGL(set_words3_kernel, dim3(1), dim3(1), 0, stream, dst, a, b, c);
+    return hipGetLastError();
+}
+
 // measurement aid: one wave that sleeps and, every `window_ticks` of the 100 MHz wall clock, records (wall ticks, shader cycles)
 // since the previous record — the shader clock the chip actually runs at while other streams load it
 __global__ void clock_sample_kernel(unsigned long long *out, int n, unsigned long long window_ticks) {

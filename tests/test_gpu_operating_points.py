@@ -221,3 +221,30 @@ def test_op_sample_philox_chi_square(hip, golden):
         chi2, pval = stats.chisquare(obs[keep], exp[keep] * obs[keep].sum() / exp[keep].sum())
         print(f"\ntemperature {temp}: chi-square over {big.sum()} classes + pooled rest, {n} draws: {chi2:.1f}, p = {pval:.3f}")
         assert big.sum() >= min_classes and pval > 1e-3
+
+
+def test_queued_stochastic_calls_keep_their_seeds(hip):
+    """64 stochastic (Philox) decodes queued on ONE stream without a synchronisation in between, each with its own seed and first clip
+    index (`gated_pixelcnn_v2.py:173-176` draws from torch's generator on every call): every call's codes equal the same call
+    run alone.  The sampler words of a call ride in the arguments of a launch queued ahead of its graph replay, not in a host
+    buffer that a later call could overwrite before the copy ran (VERDICT r4 weak #7: a 16-slot ring of pageable words)."""
+    from talkshow_amd import _lib
+    from talkshow_amd.modules import GatedPixelCNN
+    dims = dict(input_dim=256, dim=64, n_layers=3)
+    m = GatedPixelCNN(dims["input_dim"], dims["dim"], dims["n_layers"], 4, True, True).cuda()
+    m.load_state_dict(synth.to_torch(synth.pixelcnn_state_dict(seed=11, **dims)))
+    B, H, N = 4, 6, 64
+    rng = np.random.default_rng(5)
+    aud = torch.from_numpy(rng.standard_normal((B, H, 256)).astype(np.float32)).cuda()
+    label = torch.from_numpy(synth.speaker_ids(B)).cuda()
+    m.run(label, aud, mode=_lib.TS_SAMPLE_PHILOX, seed=1)          # captures the graph, checks the label range (one sync), warms up
+    torch.cuda.synchronize()
+    queued = [m.run(label, aud, mode=_lib.TS_SAMPLE_PHILOX, seed=1000 + 7 * k, clip_index0=3 * k)[0] for k in range(N)]
+    torch.cuda.synchronize()
+    queued = [q.cpu().numpy() for q in queued]
+    distinct = len({q.tobytes() for q in queued})
+    assert distinct > N // 2, f"only {distinct} distinct results in {N} calls: the seeds did not reach the sampler"
+    for k in range(N):
+        alone, _ = m.run(label, aud, mode=_lib.TS_SAMPLE_PHILOX, seed=1000 + 7 * k, clip_index0=3 * k)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(queued[k], alone.cpu().numpy(), err_msg=f"queued call {k} drew from another call's stream")
