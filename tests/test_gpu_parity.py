@@ -20,9 +20,9 @@ from talkshow_amd import synth
 pytestmark = pytest.mark.gpu
 
 # PixelCNN logits (|logit| ~ 9-30) against the reference's: the bound is 2x the largest error MEASURED on the MI355X over every
-# logits comparison of this file (profiles/r05_notes/measured_errors.jsonl); the smallest top-2 margin that decides a code in the
-# batch-32 golden is 3.4e-4, so the bound must stay well under it.
-LOGIT_ATOL = 3e-4
+# logits comparison of this file (profiles/r05_notes/measured_errors.jsonl: 9.75e-5 on the full-size network, <= 1.3e-5 on the
+# small ones); the smallest top-2 margin that decides a code in the batch-32 golden is 3.4e-4, and the bound stays under it.
+LOGIT_ATOL = 2e-4
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
