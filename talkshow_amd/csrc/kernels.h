@@ -200,7 +200,7 @@ hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long lon
 struct Knobs {
     bool conv_bands = true;     // TS_CONV_BANDS=0: big conv layers as one plain grid of 128 x 128 tiles
     bool conv_staged = true;    // TS_CONV_STAGED=0: conv_gemm_f32 stores from the accumulator registers (32 rows x 32 B per instruction) instead of whole rows through LDS
-    int conv_ring = 0;          // TS_CONV_RING=<variant>: layers that take 128 x 128 tiles run on the LDS-DMA ring engine (conv_gemm_ring.hip)
+    int conv_ring = 9;          // TS_CONV_RING=<variant>: layers that take 128 x 128 tiles run on the LDS-DMA ring engine (conv_gemm_ring.hip)
     int split_xcd = 8;          // TS_SPLIT_XCD: column-group width of conv_gemm_split's XCD-aware tile order (0: plain 2-D tile grid)
     bool prof_log = false;      // TS_PROF_LOG=1: one stderr line per conv launch while ts_prof is enabled
     bool no_graph = false;      // TS_NO_GRAPH=1: PixelCNN launches go out eagerly

@@ -23,7 +23,8 @@ ctx = _lib.context(0)
 ROUNDS = int(os.environ.get("TS_ROUNDS", "3"))
 TILES = [int(t) for t in os.environ.get("TS_TILES", "100,0,101,1,131,31,34").split(",")]
 NAMES = {100: "prod/regs-epi", 101: "reg128/regs-epi", 131: "ring k32 s2 o2/regs-epi", 0: "prod", 1: "reg128", 4: "reg64x128", 31: "ring k32 s2 o2", 32: "ring k16 s2 o4", 33: "ring k16 s3 o3", 34: "ring k16 s4 o2",
-         35: "ring k16 s2 o3", 36: "ring 64x128", 37: "ring 64x64", 38: "ring 8w 64x32", 39: "ring 8w 32x64"}
+         35: "ring k16 s2 o3", 36: "ring 64x128", 37: "ring 64x64", 38: "ring 8w 64x32", 39: "ring 8w 32x64",
+         42: "persistent 4w", 43: "persistent 8w", 44: "ring 4w stagger", 45: "ring 8w stagger"}
 # (B, L, Cin, Cout, K, tag)
 SHAPES = [
     (64, 300, 768, 2304, 1, "qkv"), (64, 300, 768, 768, 1, "out-proj"), (64, 300, 768, 3072, 1, "ffn1"), (64, 300, 3072, 768, 1, "ffn2"),
