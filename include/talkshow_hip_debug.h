@@ -42,17 +42,11 @@ int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int g
 /* Tuning / roofline entry (not part of the drop-in surface): a stride-1 conv layer (K = 1 or 3, Cin % 32 == 0)
  * whose weights are ALREADY packed on the device as [round128(Cout)][K*Cin] (tap-major, k contiguous), launched
  * `iters` times between two HIP events recorded on `stream`; tile: 0 = production heuristic, 1 = 128x128,
- * 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 with 64-deep K chunks, 6 = 160x128, 7 = 96x128; 31.. = the LDS-DMA ring engine
- * (conv_gemm_ring.hip: 31 = 128x128 with 32-deep stages and 2 ring slots, 32..35 = 16-deep stages with 2 / 3 / 4 / 2 slots, 36 = 64x128, 37 = 64x64,
- * 41 = 31 with clock stamps).  *ms_out = mean launch duration in milliseconds. */
+ * 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 with 64-deep K chunks, 6 = 160x128, 7 = 96x128; 31 / 39 = the LDS-DMA ring engine's
+ * 128x128 tile with 4 / 8 waves (conv_gemm_ring.hip).  *ms_out = mean launch duration in milliseconds. */
 int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
                        const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
                        void *stream);
-
-/* Tuning aid: device memory (8 uint64 per workgroup, max_records workgroups) where the TRACE build of conv_gemm_f32's LDS-DMA ring engine
- * (ts_op_conv1d_timed tile 41) stamps the 100 MHz wall clock: [0] entry [1] operand pointers ready [2] first stage landed [3] main loop done
- * [4] epilogue stores issued [5] stores acknowledged [6] HW_ID | XCC_ID << 32 [7] linear workgroup id + 1.  NULL switches it off. */
-int ts_debug_conv_trace(unsigned long long *dev_records, int max_records);
 
 /* Tuning entry (not part of the drop-in surface): `iters` DEPENDENT skinny_gemm launches replayed from one hipGraph;
  * *us_out = microseconds per launch.  gate != 0: N = 2K with the tanh*sigmoid epilogue; debug: unused. */

@@ -25,7 +25,6 @@ const Knobs &knobs() {
         Knobs v;
         auto num = [](const char *name, int dflt) { const char *e = std::getenv(name); return e && e[0] ? std::atoi(e) : dflt; };
         v.conv_bands = num("TS_CONV_BANDS", 1) != 0;
-        v.conv_staged = num("TS_CONV_STAGED", 1) != 0;
         v.conv_ring = num("TS_CONV_RING", 9);
         v.split_xcd = num("TS_SPLIT_XCD", 8);
         v.prof_log = num("TS_PROF_LOG", 0) != 0;
@@ -232,11 +231,6 @@ int ts_op_conv1d_timed(ts_ctx *ctx, const float *x, int B, int Lin, int Cin, con
     if (ms_out) *ms_out = ms / (iters > 0 ? iters : 1);
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
-    return 0;
-}
-
-int ts_debug_conv_trace(unsigned long long *dev_records, int max_records) {
-    TS_HIP(ts::conv_ring_trace_set(dev_records, dev_records ? max_records : 0));
     return 0;
 }
 

@@ -275,13 +275,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams &p, const int zidx, c
         buf ^= 1;
     }
 
-    // the last chunk's barrier sits behind everybody's last fragment read: the operand tiles are free to become the epilogue's slabs
-    if constexpr ((TN == 1 || TN == 2 || TN == 4) && 4 * 32 * WN <= 2 * (BM + BN) * LDS_LD) {
-        if (!p.epi_regs && conv_tile_staged_ok(p, g, tp)) {   // wave-uniform
-            conv_tile_epilogue_staged<TM, TN>(p, g, tp, acc, m0 + wm * WM, n0 + wn * WN, lane, smem + wave * (32 * WN));
-            return;
-        }
-    }
     conv_tile_epilogue<TM, TN>(p, g, tp, acc, m0 + wm * WM, n0 + wn * WN, li, lh);   // conv_tile.h
 }
 
@@ -356,18 +349,15 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) p.zero = skinny_zero_buffer(dev);
     }
-    p.epi_regs = knobs().conv_staged ? 0 : 1;
-    if (tile >= 100) {   // tuning / tests: tile id + 100 = the same tile with the register epilogue
-        p.epi_regs = 1;
-        tile -= 100;
-    }
     dim3 block(256);
     auto grid = [&](int bm, int bn) { return dim3((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, p.ngroups); };
     // zero buffer (ts::skinny_init, called by ts_ctx_create): 64 Ki floats; parked pointers walk at most Ktot floats of it
     if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000) return hipErrorInvalidValue;
-    if (tile >= 31 && tile <= 49) return launch_conv_gemm_ring(p, tile - 30, stream);   // LDS-DMA ring engine (conv_gemm_ring.hip)
-    if (tile == 0 && knobs().conv_ring > 0 && pick_tile(p) == 1 && launch_conv_gemm_ring(p, knobs().conv_ring, stream) == hipSuccess)
-        return hipSuccess;   // (a layer the ring engine does not take — segments that are not multiples of its stage depth — falls through)
+    if (tile == 31 || tile == 39) return launch_conv_gemm_ring(p, tile - 30, stream);   // LDS-DMA ring engine (conv_gemm_ring.hip)
+    // single-problem layers that take 128 x 128 tiles (the face generator's GEMMs) run on the ring engine; the paired body + hand
+    // layers keep the banded launch below (same-box A/B: profiles/r05_notes/ring_conv_stacks_ab.txt, ring_face_ab.txt)
+    if (tile == 0 && knobs().conv_ring > 0 && p.ngroups == 1 && p.zdiv == 0 && pick_tile(p) == 1 && conv_gemm_ring_takes(p))
+        return launch_conv_gemm_ring(p, knobs().conv_ring, stream);
     if (tile == 0 && pick_tile(p) == 1) {
         const bool banded = knobs().conv_bands;   // TS_CONV_BANDS=0: plain grid (A/B, tests)
         ConvBands bd;

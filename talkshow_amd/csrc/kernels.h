@@ -49,7 +49,6 @@ struct ConvParams {
     int zdiv;
     long x_zs0, x_zs1, w_zs0, w_zs1, o_zs0, o_zs1, b_zs1, r_zs0, r_zs1;
     int w_planes;        // conv_gemm_split, 2 planes only: the weights are plane images already (split_weight_planes): no split of B in the kernel
-    int epi_regs;        // set by the launchers (TS_CONV_STAGED=0): epilogue straight from the accumulator registers instead of the coalesced, LDS-staged form
     int xcd_tiles;       // set by launch_conv_gemm_split (0 or the column-group width): 1-D grid, tiles dealt to the XCDs in blocks that share operands
 };
 
@@ -60,7 +59,8 @@ struct ConvBands {
 };
 
 bool conv_gemm_band_plan(const ConvParams &p, ConvBands &bd);   // host only: the plan launch_conv_gemm(p, 0, ...) would use
-// tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 (BK 64), 6 = 160x128, 7 = 96x128 (for tuning / tests)
+// tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 (BK 64), 6 = 160x128, 7 = 96x128 (for tuning / tests);
+// 31 / 39 = the LDS-DMA ring engine's 128x128 tile with 4 / 8 waves (conv_gemm_ring.hip)
 hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream);
 // the same convolution on the bf16 matrix cores with fp32 operands split into `planes` bf16 terms (2: three products, ~2^-16;
 // 3: six products, fp32 grade) — conv_gemm_split.hip; an opt-in plan for tolerance-only GEMMs (the face generator)
@@ -199,8 +199,7 @@ hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long lon
 // ------------------------------------------------------------------------------------------------
 struct Knobs {
     bool conv_bands = true;     // TS_CONV_BANDS=0: big conv layers as one plain grid of 128 x 128 tiles
-    bool conv_staged = true;    // TS_CONV_STAGED=0: conv_gemm_f32 stores from the accumulator registers (32 rows x 32 B per instruction) instead of whole rows through LDS
-    int conv_ring = 9;          // TS_CONV_RING=<variant>: layers that take 128 x 128 tiles run on the LDS-DMA ring engine (conv_gemm_ring.hip)
+    int conv_ring = 9;          // TS_CONV_RING=0|1|9: single-problem layers that take 128 x 128 tiles on conv_gemm.hip / the ring engine with 4 / 8 waves (conv_gemm_ring.hip)
     int split_xcd = 8;          // TS_SPLIT_XCD: column-group width of conv_gemm_split's XCD-aware tile order (0: plain 2-D tile grid)
     bool prof_log = false;      // TS_PROF_LOG=1: one stderr line per conv launch while ts_prof is enabled
     bool no_graph = false;      // TS_NO_GRAPH=1: PixelCNN launches go out eagerly

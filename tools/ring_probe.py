@@ -5,9 +5,9 @@ at 256 clips, and exact-round shapes (no tail) at three depths for a per-stage /
 
 Variants are interleaved inside one process, `ROUNDS` rounds each (guide rule 24); per (shape, variant): median and best mean
 launch duration (HIP events on the launch stream, 20 launches per measurement) and TFLOP/s; the ring outputs are compared with
-tile 1's bit for bit (same MFMA, same k order).
-Tile id + 100 = the same launch with the epilogue that stores straight from the accumulator registers (rounds 1-4) instead of the
-coalesced, LDS-staged one."""
+tile 1's bit for bit (same MFMA, same k order).  The variants that were measured with this tool and set aside (16-deep stages with 2-4
+ring slots, 64 x 128 / 64 x 64 tiles, persistent workgroups, staggered start, whole-row stores through LDS) live in
+tools/experiments/conv_ring/ with their numbers in profiles/r05_notes/."""
 import ctypes as C
 import os
 import sys
@@ -21,10 +21,8 @@ from talkshow_amd import _lib  # noqa: E402
 lib = _lib.load()
 ctx = _lib.context(0)
 ROUNDS = int(os.environ.get("TS_ROUNDS", "3"))
-TILES = [int(t) for t in os.environ.get("TS_TILES", "100,0,101,1,131,31,34").split(",")]
-NAMES = {100: "prod/regs-epi", 101: "reg128/regs-epi", 131: "ring k32 s2 o2/regs-epi", 0: "prod", 1: "reg128", 4: "reg64x128", 31: "ring k32 s2 o2", 32: "ring k16 s2 o4", 33: "ring k16 s3 o3", 34: "ring k16 s4 o2",
-         35: "ring k16 s2 o3", 36: "ring 64x128", 37: "ring 64x64", 38: "ring 8w 64x32", 39: "ring 8w 32x64",
-         42: "persistent 4w", 43: "persistent 8w", 44: "ring 4w stagger", 45: "ring 8w stagger"}
+TILES = [int(t) for t in os.environ.get("TS_TILES", "0,1,31,39").split(",")]
+NAMES = {0: "prod", 1: "reg128", 4: "reg64x128", 31: "ring 4w", 39: "ring 8w"}
 # (B, L, Cin, Cout, K, tag)
 SHAPES = [
     (64, 300, 768, 2304, 1, "qkv"), (64, 300, 768, 768, 1, "out-proj"), (64, 300, 768, 3072, 1, "ffn1"), (64, 300, 3072, 768, 1, "ffn2"),
