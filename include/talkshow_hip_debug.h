@@ -48,6 +48,10 @@ int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin,
                        const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
                        void *stream);
 
+/* Test aid: how many captured hipGraphs the PixelCNN keeps for `stream` right now (whole-call graphs of repeated shapes + the chunk
+ * graphs that serve first-time shapes of any length; bounded, least recently used out first), or -1. */
+int ts_debug_pixelcnn_graphs(ts_pixelcnn *pix, void *stream);
+
 /* Tuning entry (not part of the drop-in surface): `iters` DEPENDENT skinny_gemm launches replayed from one hipGraph;
  * *us_out = microseconds per launch.  gate != 0: N = 2K with the tanh*sigmoid epilogue; debug: unused. */
 int ts_debug_skinny_chain(ts_ctx *ctx, int M, int K, int gate, int iters, int debug, float *us_out);

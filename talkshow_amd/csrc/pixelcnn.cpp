@@ -82,12 +82,38 @@ struct ts_pixelcnn {
         // every pointer inside the captured kernels is one of the buffers above or the staging buffers below, so a graph
         // is valid for any caller pointers; key = (B, H, H0, mode)
         DevBuf codes_int, unif_int, dyn;   // dyn: {seed, clip0, position base} of the call being replayed, written by a kernel ahead of it
+        DevBuf cAEH, cAEH1, cAV1C, cAV1P;  // the audio terms of ONE chunk of rows, compact (chunked one-shot calls: see run_chunked)
         hipStream_t cap_stream = nullptr;
-        std::map<std::tuple<int, int, int, int>, hipGraphExec_t> graphs;
-        std::map<std::tuple<int, int, int, int>, std::pair<long, double>> graph_stats;   // skinny launches, flops
+        // Captured graphs, least recently used out first: at most GRAPH_CAP per Work.  Keys: (B, H, H0, mode) = a whole one-shot call;
+        // (B, Hc, -(1 + phase), mode) = Hc rows of a chunked one-shot call; (B, Hc, 1000 + phase, mode) = a streaming step.
+        typedef std::tuple<int, int, int, int> Key;
+        struct Entry {
+            hipGraphExec_t exec;
+            uint64_t used;
+        };
+        static constexpr size_t GRAPH_CAP = 24;
+        std::map<Key, Entry> graphs;
+        std::map<Key, std::pair<long, double>> graph_stats;   // skinny launches, flops
+        std::map<Key, int> seen;                              // one-shot shapes met so far (a shape gets its own whole-call graph the second time)
+        uint64_t tick = 0;
         void drop_graphs() {
-            for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second);
+            for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second.exec);
             graphs.clear();
+            graph_stats.clear();
+        }
+        // room for one more graph: the least recently used one goes (after the stream it may still be running on has drained)
+        int make_room(hipStream_t s) {
+            while (graphs.size() >= GRAPH_CAP) {
+                auto lru = graphs.begin();
+                for (auto it = graphs.begin(); it != graphs.end(); ++it)
+                    if (it->second.used < lru->second.used) lru = it;
+                TS_HIP(hipStreamSynchronize(s));
+                (void)hipGraphExecDestroy(lru->second.exec);
+                graph_stats.erase(lru->first);
+                graphs.erase(lru);
+            }
+            if (seen.size() > 4096) seen.clear();
+            return 0;
         }
         ~Work() {
             drop_graphs();
@@ -115,6 +141,10 @@ int upload_vec(std::vector<std::unique_ptr<DevBuf>> &dst, const std::vector<floa
     dst.emplace_back(new DevBuf());
     return dst.back()->upload(v.data(), v.size() * sizeof(float));
 }
+
+// rows per graph of a chunked one-shot call: a multiple of 4 (the period of the row rings), so that every chunk after the first
+// starts in the same buffer phase
+constexpr int CHUNK_ROWS = 8;
 
 int ensure_work(ts_pixelcnn *p, ts_pixelcnn::Work *w, int B, int Htot) {
     if (B <= w->capB && Htot <= w->capH) return 0;
@@ -147,6 +177,10 @@ int ensure_work(ts_pixelcnn *p, ts_pixelcnn::Work *w, int B, int Htot) {
     TS_TRY(w->codes_int.ensure((size_t)cb * ch * 2 * sizeof(int64_t)));
     TS_TRY(w->unif_int.ensure((size_t)cb * ch * 2 * sizeof(float)));
     TS_TRY(w->dyn.ensure(3 * sizeof(uint64_t)));
+    TS_TRY(w->cAEH.ensure((size_t)cb * CHUNK_ROWS * D * f));
+    TS_TRY(w->cAEH1.ensure((size_t)cb * CHUNK_ROWS * 2 * D * f));
+    TS_TRY(w->cAV1C.ensure((size_t)cb * CHUNK_ROWS * 4 * D * f));
+    TS_TRY(w->cAV1P.ensure((size_t)cb * CHUNK_ROWS * 4 * D * f));
     w->drop_graphs();   // buffers moved: captured pointers are stale
     w->capB = cb;
     w->capH = ch;
@@ -170,13 +204,20 @@ struct RunCfg {
     int pos_r0;            // Philox position of row r, column j = pos_base + (r - pos_r0) * 2 + j
     long pos_base;         // (added on the device from a dynamic word when a captured graph is replayed)
     int last_row;          // rows >= last_row are never generated: look-ahead partial sums for them are skipped
+    // where the audio terms of rows [aud_r0, aud_r0 + aud_rows) live (the Work's whole-call buffers unless a chunk brings its own)
+    const float *aeh = nullptr, *aeh1 = nullptr, *av1c = nullptr, *av1p = nullptr;
+    // the caller's codes / uniforms arrays hold out_H rows per clip, of which this run fills rows out_row0 .. out_row0 + H - 1
+    int out_H = 0, out_row0 = 0;
+    void audio_from(ts_pixelcnn::Work *wk) { aeh = wk->AEH.f(), aeh1 = wk->AEH1.f(), av1c = wk->AV1C.f(), av1p = wk->AV1P.f(); }
 };
 inline RunCfg one_shot_cfg(int B, int H, int H0, int mode, const float *uniforms, uint64_t seed, int64_t clip0, int64_t *codes,
                            float *logits, ts_pixelcnn::Work *w) {
     const int Htot = H0 + H;
     // Philox position of code (r, j) = 2 r + j with r counted from the first PREFIX row: a call that continues another one
     // behind its codes (`infer(chunk1, pre_latents=chunk0 codes)`) draws the next numbers of the stream, not chunk 0's again
-    return RunCfg{B, H, H0, Htot, mode, uniforms, seed, clip0, codes, logits, nullptr, w, Htot, 0, Htot, H0, 0, 0, Htot};
+    RunCfg c{B, H, H0, Htot, mode, uniforms, seed, clip0, codes, logits, nullptr, w, Htot, 0, Htot, H0, 0, 0, Htot};
+    c.audio_from(w);
+    return c;
 }
 
 SkinnyParams base_params(int M, int N, int epi) {
@@ -343,7 +384,7 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
             g.bias = p->bv[l]->f();        // nothing above the first row
         }
         if (l == 1) {
-            g.add2 = w->AV1C.f() + arow;   // Wcur_1 . [AEV[r] | AEV[r]]
+            g.add2 = c.av1c + arow;        // Wcur_1 . [AEV[r] | AEV[r]]
             g.add2_stride = astride;
         }
         gate_common(g, l);
@@ -355,7 +396,7 @@ void build_vertical(ts_pixelcnn *p, const RunCfg &c, int r, std::vector<Slot> &o
             q.ldw = 2 * D;
             q.bias = p->bv[l]->f();
             if (l == 1) {
-                q.add1 = w->AV1P.f() + arow;   // Wprev_1 . [AEV[r] | AEV[r]]
+                q.add1 = c.av1p + arow;        // Wprev_1 . [AEV[r] | AEV[r]]
                 q.add1_stride = astride;
             }
             q.out = P(l, (r + 1) & 1);
@@ -421,7 +462,7 @@ void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector
         a.ldw = D;
         a.bias = p->rb[l]->f();
         if (l == 1) {
-            a.add1 = w->AEH.f() + (size_t)(r - c.aud_r0) * D;
+            a.add1 = c.aeh + (size_t)(r - c.aud_r0) * D;
             a.add1_stride = (long)c.aud_rows * D;
         } else {
             a.add1 = XH(l - 1, j);
@@ -440,7 +481,7 @@ void build_horizontal(ts_pixelcnn *p, const RunCfg &c, int r, int j, std::vector
         g.add1 = V2H(l);
         g.add1_stride = 4 * D;
         if (l == 1) {
-            g.add2 = w->AEH1.f() + (size_t)(r - c.aud_r0) * 2 * D;
+            g.add2 = c.aeh1 + (size_t)(r - c.aud_r0) * 2 * D;
             g.add2_stride = (long)c.aud_rows * 2 * D;
         }
         if (j == 1) {
@@ -804,6 +845,12 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
 }
 void ts_pixelcnn_destroy(ts_pixelcnn *p) { delete p; }
 
+int ts_debug_pixelcnn_graphs(ts_pixelcnn *p, void *stream) {
+    if (!p) return -1;
+    ts_pixelcnn::Work *w = p->works.find((hipStream_t)stream);
+    return w ? (int)w->graphs.size() : 0;
+}
+
 int ts_pixelcnn_graph_stats(ts_pixelcnn *p, void *stream, int B, int H, int mode, int64_t *launches, double *flops) {
     if (!p) return fail("ts_pixelcnn_graph_stats: null argument");
     ts_pixelcnn::Work *w = p->works.find((hipStream_t)stream);
@@ -853,11 +900,13 @@ int class_rows(ts_pixelcnn *p, ts_pixelcnn::Work *w, const int64_t *label, int B
 
 // Runs rows [r_begin, r_end) of `c`: eagerly, or as a replay of the hipGraph captured for `key` (host launch cost would
 // otherwise dominate: ~37 dependent tiny launches per row).  On the graph path the kernels write codes into the Work's
-// staging buffer (every pointer inside a captured kernel is a Work buffer, so a graph is valid for any caller pointers).
-int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const std::tuple<int, int, int, int> &key,
+// staging buffer (every pointer inside a captured kernel is a Work buffer, so a graph is valid for any caller pointers);
+// the caller's arrays hold c.out_H rows per clip, of which this run covers rows c.out_row0 .. c.out_row0 + c.H - 1.
+int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const ts_pixelcnn::Work::Key &key,
              const float *uniforms, int64_t *codes, hipStream_t s) {
     ts_ctx *ctx = p->ctx;
     ts_pixelcnn::Work *w = c.w;
+    const int out_H = c.out_H > 0 ? c.out_H : c.H;
     auto row_loop = [&](hipStream_t st) -> int {
         for (int r = r_begin; r < r_end; ++r) {
             const bool need_h = r >= c.out_r0 && !(c.mode == TS_TEACHER_FORCED && !c.logits);   // prefix rows only feed the row cache
@@ -866,6 +915,7 @@ int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const
         return 0;
     };
     if (!graph) {
+        if (out_H != c.H) return fail("pixelcnn: eager rows write the caller's arrays whole");
         c.codes = codes;
         c.uniforms = uniforms;
         return row_loop(s);
@@ -874,12 +924,14 @@ int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const
     c.uniforms = c.mode == TS_SAMPLE_UNIFORMS ? w->unif_int.f() : nullptr;
     c.dyn = static_cast<const uint64_t *>(w->dyn.p);
     if (c.mode == TS_SAMPLE_UNIFORMS)
-        TS_HIP(hipMemcpyAsync(w->unif_int.p, uniforms, (size_t)c.B * c.H * 2 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        TS_HIP(hipMemcpy2DAsync(w->unif_int.p, (size_t)c.H * 2 * sizeof(float), uniforms + (size_t)c.out_row0 * 2,
+                                (size_t)out_H * 2 * sizeof(float), (size_t)c.H * 2 * sizeof(float), c.B, hipMemcpyDeviceToDevice, s));
     // the call's sampler words travel as the ARGUMENTS of a one-thread launch (copied when the launch is queued): no host buffer
     // has to stay intact behind the call, so any number of calls may be queued on the stream without a synchronisation
     TS_HIP(launch_set_words3(static_cast<uint64_t *>(w->dyn.p), c.seed, (uint64_t)c.clip0, (uint64_t)c.pos_base, s));
     auto it = w->graphs.find(key);
     if (it == w->graphs.end()) {
+        TS_TRY(w->make_room(s));
         if (!w->cap_stream) TS_HIP(hipStreamCreateWithFlags(&w->cap_stream, hipStreamNonBlocking));
         hipGraph_t g = nullptr;
         const long l0 = ctx->n_launch[FAM_SKINNY];
@@ -897,10 +949,43 @@ int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const
         const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (ei != hipSuccess) return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
-        it = w->graphs.emplace(key, ex).first;
+        it = w->graphs.emplace(key, ts_pixelcnn::Work::Entry{ex, 0}).first;
     }
-    TS_HIP(hipGraphLaunch(it->second, s));
-    TS_HIP(hipMemcpyAsync(codes, w->codes_int.p, (size_t)c.B * c.H * 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    it->second.used = ++w->tick;
+    TS_HIP(hipGraphLaunch(it->second.exec, s));
+    TS_HIP(hipMemcpy2DAsync(codes + (size_t)c.out_row0 * 2, (size_t)out_H * 2 * sizeof(int64_t), w->codes_int.p,
+                            (size_t)c.H * 2 * sizeof(int64_t), (size_t)c.H * 2 * sizeof(int64_t), c.B, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// A one-shot call (no prefix) as a sequence of CHUNK_ROWS-row graphs: the reference's own evaluation loop
+// (scripts/test_body.py:113-194) feeds clips of arbitrary lengths, and a whole-call graph per length would cost a capture +
+// instantiate of ~36 H nodes for every new H and keep them all.  A chunk's graph depends on (B, rows in the chunk, buffer
+// phase of its first row, mode) only — the streaming sessions' construction (ts_pixelcnn_stream_step): a 4-row token ring, rows
+// indexed absolutely, the Philox position base a device word — so two graphs (first chunk, later chunks) plus one or two for the
+// short last chunk serve every clip length.  The audio terms were computed for the whole call; a chunk's rows are copied into the
+// compact chunk buffers its graph reads.  Bit-identical to the whole-call graph (same launches, same order, same rings: only the
+// look-ahead partial sums of rows past the end are computed and never read).
+int run_chunked(ts_pixelcnn *p, ts_pixelcnn::Work *w, int B, int H, int mode, const float *uniforms, uint64_t seed, int64_t clip0,
+                int64_t *codes, hipStream_t s) {
+    const size_t D = p->D, f = sizeof(float);
+    constexpr int RING = 4;
+    for (int r0 = 0; r0 < H; r0 += CHUNK_ROWS) {
+        const int Hc = std::min(CHUNK_ROWS, H - r0);
+        RunCfg c{B, Hc, 0, r0 + Hc, mode, nullptr, seed, clip0, nullptr, nullptr, nullptr, w,
+                 RING, r0, Hc, r0, r0, 2l * r0, 0x7fffffff};
+        c.aeh = w->cAEH.f(), c.aeh1 = w->cAEH1.f(), c.av1c = w->cAV1C.f(), c.av1p = w->cAV1P.f();
+        c.out_H = H;
+        c.out_row0 = r0;
+        struct { const DevBuf *src; DevBuf *dst; size_t width; } rows[4] = {
+            {&w->AEH, &w->cAEH, D}, {&w->AEH1, &w->cAEH1, 2 * D}, {&w->AV1C, &w->cAV1C, 4 * D}, {&w->AV1P, &w->cAV1P, 4 * D}};
+        for (auto &m : rows)
+            if (p->NL > 1 || m.src == &w->AEH)
+                TS_HIP(hipMemcpy2DAsync(m.dst->p, (size_t)Hc * m.width * f, m.src->f() + (size_t)r0 * m.width, (size_t)H * m.width * f,
+                                        (size_t)Hc * m.width * f, B, hipMemcpyDeviceToDevice, s));
+        const int phase = r0 < 3 ? r0 : 3 + (r0 % 4);
+        TS_TRY(run_rows(p, c, r0, r0 + Hc, true, std::make_tuple(B, Hc, -(1 + phase), mode), uniforms, codes, s));
+    }
     return 0;
 }
 
@@ -950,7 +1035,12 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
                                     (size_t)H * 2 * e, B, hipMemcpyDeviceToDevice, s));
         TS_HIP(launch_i64_to_i32(tf, w->tok32.i(), (long)B * Htot * 2, s));
     }
-    return run_rows(p, c, 0, Htot, graph, std::make_tuple(B, H, H0, mode), uniforms, codes, s);
+    const ts_pixelcnn::Work::Key key = std::make_tuple(B, H, H0, mode);
+    // A shape met for the first time runs as chunk graphs (two or three small captures that serve every clip length); the second
+    // time it gets its own whole-call graph (one replay per call: the serving loops, bench.py).  The cache is bounded either way.
+    if (graph && H0 == 0 && !w->graphs.count(key) && w->seen[key]++ == 0 && H > CHUNK_ROWS)
+        return run_chunked(p, w, B, H, mode, uniforms, seed, clip0, codes, s);
+    return run_rows(p, c, 0, Htot, graph, key, uniforms, codes, s);
 }
 
 // ---- streaming generation (reference: the pre_latents / pre_audio prefix of gated_pixelcnn_v2.py:158-165
@@ -994,6 +1084,7 @@ int ts_pixelcnn_stream_step(ts_pixelcnn_stream *st, const float *aud, int Hc, in
     TS_TRY(audio_terms(p, w, aud, B, Hc, s));
     RunCfg c{B, Hc, 0, r0 + Hc, mode, nullptr, seed, clip0, nullptr, nullptr, nullptr, w,
              RING, r0, Hc, r0, r0, 2l * r0, 0x7fffffff};
+    c.audio_from(w);
     // a captured chunk is valid for every start row with the same buffer phases (parity of the per-layer row cache, slot
     // in the 4-row rings) and the same set of existing rows above (rows 0..2 have fewer): key on that, not on r0
     const int phase = r0 < 3 ? r0 : 3 + (r0 % 4);

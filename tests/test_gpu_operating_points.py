@@ -248,3 +248,57 @@ def test_queued_stochastic_calls_keep_their_seeds(hip):
         alone, _ = m.run(label, aud, mode=_lib.TS_SAMPLE_PHILOX, seed=1000 + 7 * k, clip_index0=3 * k)
         torch.cuda.synchronize()
         np.testing.assert_array_equal(queued[k], alone.cpu().numpy(), err_msg=f"queued call {k} drew from another call's stream")
+
+
+def test_arbitrary_clip_lengths_bounded_graph_cache(hip):
+    """The reference's evaluation loop feeds clips of arbitrary lengths with B = 2 (`scripts/test_body.py:113-194`).  120 distinct
+    lengths through the graph path: a shape met for the first time runs as chunk graphs that do not depend on the length (so a new
+    length costs no new capture once the chunk graphs exist), a shape met again gets its own whole-call graph, and the cache never
+    holds more than its cap (one ~36 H-node graph per distinct length, kept forever).  The chunked run, the
+    whole-call replay and the oracle agree bit for bit."""
+    import time
+    from talkshow_amd import _lib
+    from talkshow_amd.modules import GatedPixelCNN
+    lib = hip[1]
+    dims = dict(input_dim=256, dim=64, n_layers=3)
+    sd = synth.pixelcnn_state_dict(seed=21, **dims)
+    m = GatedPixelCNN(dims["input_dim"], dims["dim"], dims["n_layers"], 4, True, True).cuda()
+    m.load_state_dict(synth.to_torch(sd))
+    B = 2
+    rng = np.random.default_rng(9)
+    label = torch.from_numpy(synth.speaker_ids(B)).cuda()
+    stream = _lib.stream_ptr()
+    lengths = list(range(9, 129))
+    rng.shuffle(lengths)
+    auds = {H: torch.from_numpy(rng.standard_normal((B, H, 256)).astype(np.float32)).cuda() for H in lengths}
+    first, wall = {}, []
+    for H in lengths:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        first[H] = m.run(label, auds[H], mode=_lib.TS_SAMPLE_GREEDY)[0]
+        torch.cuda.synchronize()
+        wall.append((time.perf_counter() - t0) / H)
+        assert 0 < lib.ts_debug_pixelcnn_graphs(m.handle(), stream) <= 24
+    n_chunk_graphs = lib.ts_debug_pixelcnn_graphs(m.handle(), stream)
+    assert n_chunk_graphs <= 2 + 2 * 7, f"{n_chunk_graphs} graphs after 120 first-time lengths: chunk graphs must not depend on the length"
+    # per-row wall time of the late first-time calls is what it was for the early ones (no capture of a length-sized graph per call)
+    early, late = np.median(wall[5:25]), np.median(wall[-20:])
+    assert late < 1.5 * early, f"per-row wall time grew from {early * 1e6:.1f} to {late * 1e6:.1f} us"
+    # second visit: whole-call graphs, least recently used out first; same bits as the chunked run
+    for H in lengths[:40]:
+        again = m.run(label, auds[H], mode=_lib.TS_SAMPLE_GREEDY)[0]
+        assert torch.equal(again, first[H]), f"H = {H}: whole-call graph and chunk graphs disagree"
+        assert lib.ts_debug_pixelcnn_graphs(m.handle(), stream) <= 24
+    # stochastic decode through the chunk graphs: the Philox position of a code is its absolute (row, column)
+    H = 77
+    aud = torch.from_numpy(rng.standard_normal((B, H, 256)).astype(np.float32)).cuda()
+    c1 = m.run(label, aud, mode=_lib.TS_SAMPLE_PHILOX, seed=5, clip_index0=3)[0]       # chunked (first visit of this shape / mode)
+    c2 = m.run(label, aud, mode=_lib.TS_SAMPLE_PHILOX, seed=5, clip_index0=3)[0]       # whole-call graph
+    assert torch.equal(c1, c2)
+    u = O.philox_uniforms(5, 3, B, H)
+    c3 = m.run(label, aud, mode=_lib.TS_SAMPLE_UNIFORMS, uniforms=u)[0]                # chunked, uniforms copied in chunk by chunk
+    assert torch.equal(c1, c3)
+    for Hs in (9, 37):   # against the oracle's full-grid generate
+        a = auds[Hs].cpu().numpy()
+        ref = O.pixelcnn_generate(label.cpu().numpy(), np.repeat(a.transpose(0, 2, 1)[:, :, :, None], 2, axis=3), sd, dims["n_layers"], Hs)
+        np.testing.assert_array_equal(first[Hs].cpu().numpy(), ref)
