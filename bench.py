@@ -472,6 +472,7 @@ def main_whole_body(a, world, rank, local, dist):
     from talkshow_amd import _lib, synth
     from talkshow_amd import parallel
     import types
+    coll = world > 1 or os.environ.get("TS_BENCH_FORCE_COLLECTIVES", "0") == "1"   # (world 1 over RCCL: tools/rccl_smoke.sh)
     w, sds = build_models(local)
     face = types.SimpleNamespace(generator=build_face(local))
     dev = torch.device("cuda", local)
@@ -490,23 +491,23 @@ def main_whole_body(a, world, rank, local, dist):
                                          batch_body=a.batch * a.coalesce, batch_face=64)
 
     def barrier():
-        if world > 1:
+        if coll:
             dist.barrier()
 
     for _ in range(max(1, a.warmup)):
         rows = step()
-    if world > 1:
+    if coll:
         parallel.gather_sequences(rows, N)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         rows = step()
-        allrows = parallel.gather_sequences(rows, N) if world > 1 else rows
+        allrows = parallel.gather_sequences(rows, N) if coll else rows
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if coll:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -664,19 +665,23 @@ class BodyJob:
             out["cpu_baseline"] = cpu_baseline(self.sds, 1000)
 
 
-def run_contract(job, dist, world, rank, steps, warmup, clock=time.perf_counter):
+def run_contract(job, dist, world, rank, steps, warmup, clock=time.perf_counter, collectives=None):
     """The bench contract's control flow, device-agnostic: W untimed warm-up steps, then EXACTLY `steps` steps bracketed by
     barrier + synchronize on both sides, the job's one exchange inside the bracket (N > 1), MAX over ranks.  Every collective
     of the job sits in here; the caller destroys the process group before rank 0 starts its extra measurement legs, so no rank
-    ever waits in a collective for them.  Returns (seconds, compute seconds on this rank, exchange info or None)."""
+    ever waits in a collective for them.  Returns (seconds, compute seconds on this rank, exchange info or None).
+    `collectives=True` takes the N > 1 code path at world 1 too (TS_BENCH_FORCE_COLLECTIVES=1: the RCCL plumbing check that one
+    metered GPU allows — process group on the `nccl` backend, barriers, the all-gather, the MAX all-reduce)."""
+    coll = world > 1 if collectives is None else collectives
+
     def barrier():
-        if world > 1:
+        if coll:
             dist.barrier()
 
     job.warm(steps)
     job.run_steps(max(warmup, 1))            # W untimed steps (passes of sizes the warm-up above has seen or captures now)
     job.sync()
-    if world > 1:
+    if coll:
         job.gather()                         # the exchange once untimed: RCCL sets up its rings / buffers on first use
         job.sync()
     barrier()
@@ -685,27 +690,39 @@ def run_contract(job, dist, world, rank, steps, warmup, clock=time.perf_counter)
     job.sync()
     t_compute = clock() - t0
     info = None
-    if world > 1:
+    if coll:
         info = job.gather()
         job.sync()
         info.update({"ranks_seen": world, "gather_ms": (clock() - t0 - t_compute) * 1e3, "compute_ms": t_compute * 1e3,
                      "note": "rank 0's clock; the headline takes the max over ranks of compute + gather"})
     barrier()
     dt = clock() - t0
-    if world > 1:
+    if coll:
         tmax = job.scalar(dt)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     return dt, t_compute, info
 
 
-def finish(job, dist, world, rank, steps, warmup, dt, info, emit=print):
+def finish(job, dist, world, rank, steps, warmup, dt, info, emit=print, collectives=None):
     """After the timed region: every rank checks what it timed (local work), the ranks leave the process group TOGETHER, and only
-    then does rank 0 run its extra legs and print the one JSON line.  Ranks != 0 run nothing else."""
-    check = job.selfcheck()
-    if world > 1:
+    then does rank 0 run its extra legs and print the one JSON line.  Ranks != 0 run nothing else.  A rank whose check fails does
+    not leave the others waiting in a barrier: the failure is all-reduced first, every rank leaves the group, every rank raises."""
+    coll = world > 1 if collectives is None else collectives
+    failure = None
+    try:
+        check = job.selfcheck()
+    except Exception as e:                      # noqa: BLE001 — re-raised below, after the group has been left together
+        failure, check = e, None
+    if coll:
+        bad = job.scalar(1.0 if failure is not None else 0.0)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         dist.barrier()
         dist.destroy_process_group()
+        if failure is None and float(bad.item()) > 0:
+            failure = RuntimeError("selfcheck failed on another rank")
+    if failure is not None:
+        raise failure
     if rank != 0:
         return None
     frames = world * steps * job.frames_per_step()
@@ -753,19 +770,25 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local)
     import torch.distributed as dist
-    if world > 1:
+    # TS_BENCH_FORCE_COLLECTIVES=1 (tools/rccl_smoke.sh): the N > 1 code path — RCCL process group, barriers, the all-gather of every
+    # step's rows, the MAX all-reduce — at world 1, which is all one metered GPU allows; the line then carries an `rccl` block
+    coll = world > 1 or os.environ.get("TS_BENCH_FORCE_COLLECTIVES", "0") == "1"
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if a.config == "whole_body":
         main_whole_body(a, world, rank, local, dist)
-        if world > 1:
+        if coll:
             dist.barrier()
             dist.destroy_process_group()
         return
 
     job = BodyJob(a, world, rank, local)
-    dt, _, info = run_contract(job, dist, world, rank, a.steps, a.warmup)
-    finish(job, dist, world, rank, a.steps, a.warmup, dt, info, emit=lambda line: print(line, flush=True))
+    dt, _, info = run_contract(job, dist, world, rank, a.steps, a.warmup, collectives=coll)
+    finish(job, dist, world, rank, a.steps, a.warmup, dt, info, emit=lambda line: print(line, flush=True), collectives=coll)
 
 
 if __name__ == "__main__":

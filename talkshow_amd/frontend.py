@@ -160,16 +160,19 @@ def create_dct(n_mfcc, n_mels):
     return dct.T.astype(F32)
 
 
-def power_spectrogram(wave, n_fft=2048, hop_length=734):
-    """torchaudio.transforms.Spectrogram(n_fft, hop_length, power=2) == |torch.stft(..., window=hann_window(n_fft,
+def power_spectrogram(wave, n_fft=2048, hop_length=734, win_length=None):
+    """torchaudio.transforms.Spectrogram(n_fft, win_length, hop_length, power=2) == |torch.stft(..., window=hann_window(win_length,
     periodic=True), center=True, pad_mode='reflect', onesided=True)|^2 on a mono waveform (N,) -> (T, n_fft//2+1),
-    T = N // hop + 1.  This stage IS pinned: tests/test_frontend.py compares it with torch.stft (installed), the function
-    torchaudio's Spectrogram calls."""
+    T = N // hop + 1; a window shorter than n_fft sits centred in the frame (torch.stft pads it with zeros on both sides).
+    This stage IS pinned: tests/test_frontend.py compares it with torch.stft (installed), the function torchaudio's Spectrogram calls."""
     from scipy import fft as sfft
     x = np.pad(np.asarray(wave, dtype=F32), (n_fft // 2, n_fft // 2), mode="reflect")
     T = 1 + (x.shape[0] - n_fft) // hop_length
     frames = np.lib.stride_tricks.sliding_window_view(x, n_fft)[::hop_length][:T]
-    window = (0.5 - 0.5 * np.cos(2.0 * math.pi * np.arange(n_fft) / n_fft)).astype(F32)          # periodic Hann
+    wl = n_fft if win_length is None else int(win_length)
+    window = np.zeros(n_fft, F32)
+    left = (n_fft - wl) // 2
+    window[left:left + wl] = (0.5 - 0.5 * np.cos(2.0 * math.pi * np.arange(wl) / wl)).astype(F32)   # periodic Hann
     spec = sfft.rfft(frames * window[None, :], axis=1)                                             # float32 -> complex64
     return (spec.real.astype(F32) ** 2 + spec.imag.astype(F32) ** 2).astype(F32)                  # (T, 1025)
 
@@ -180,6 +183,24 @@ def mfcc_from_power(power, sample_rate, n_mfcc=64, n_fft=2048, n_mels=256, top_d
     db = (10.0 * np.log10(np.maximum(mel, F32(1e-10)))).astype(F32)                                # ref = 1 -> no offset
     db = np.maximum(db, db.max() - F32(top_db))                                                    # per-clip max
     return np.ascontiguousarray((db @ create_dct(n_mfcc, n_mels)).T, dtype=F32)
+
+
+def mel_spectrogram(wave, sample_rate, n_fft=2048, hop_length=734, n_mels=256, win_length=None):
+    """torchaudio.transforms.MelSpectrogram(sample_rate, n_fft, win_length, hop_length, n_mels) with its defaults (f_min 0, f_max
+    sample_rate // 2, power 2, HTK scale, no filter normalisation) on a mono waveform (N,) -> (n_mels, T)  [`utils.py:178-191`]."""
+    power = power_spectrogram(wave, n_fft, hop_length, win_length)
+    return np.ascontiguousarray((power @ melscale_fbanks(n_fft // 2 + 1, 0.0, float(sample_rate // 2), n_mels, sample_rate)).T, dtype=F32)
+
+
+def audio_chunking(audio, frame_rate=30, chunk_size=16000):
+    """`utils.py:133-145`: (1, N) samples -> (chunks, chunk_size): one window of `chunk_size` samples per video frame, centred on it
+    (the signal zero-padded by half a window minus half a frame on both sides)."""
+    audio = np.asarray(audio, dtype=F32).reshape(1, -1)
+    spf = chunk_size // frame_rate
+    pad = (chunk_size - spf) // 2
+    x = np.pad(audio, ((0, 0), (pad, pad)))
+    anchors = range(chunk_size // 2, x.shape[-1] - chunk_size // 2, spf)
+    return np.concatenate([x[:, i - chunk_size // 2:i + chunk_size // 2] for i in anchors], axis=0)
 
 
 def mfcc(wave, sample_rate, n_mfcc=64, n_fft=2048, hop_length=734, n_mels=256, top_db=80.0):
@@ -260,9 +281,18 @@ def get_mfcc_ta(aud_fn, eps=1e-6, fps=15, smlpx=False, sr=16000, n_mfcc=64, win_
         raise NotImplementedError("encoder_choice='onset' needs librosa.onset.onset_detect (third-party, absent; no shipped "
                                   "config uses it)")
     feat = _features_from_any(aud_fn)
+    if feat is None and type in ('mel', 'mel_mul'):
+        # the two other feature types of `utils.py:178-191` (no shipped config asks for them: they run on the host, in numpy)
+        wave = _load_mono_resampled(aud_fn, sr)
+        if type == 'mel':                                               # (T, 256) mel power spectrogram
+            return mel_spectrogram(wave, sr, hop_length=_hop(fps)).T.copy()
+        wave = F32(0.01) * wave / np.mean(np.abs(wave), dtype=F32)      # 'mel_mul': one 1 s window per video frame, 10 ms hop, log
+        chunks = audio_chunking(wave, frame_rate=fps, chunk_size=sr)
+        mels = np.stack([mel_spectrogram(c, sr, hop_length=int(sr / 100), win_length=int(sr / 20)) for c in chunks])
+        return np.log(np.maximum(mels, F32(1e-10))).astype(F32)         # (chunks, 256, 101)
     if feat is None:
         if type != 'mfcc':
-            raise NotImplementedError("only type='mfcc' is on the inference path")
+            raise NotImplementedError(f"get_mfcc_ta: unknown feature type {type!r} (the reference knows 'mfcc', 'mel', 'mel_mul')")
         use_host = host if host is not None else not torch.cuda.is_available()
         if use_host:
             feat = mfcc(_load_mono_resampled(aud_fn, sr), sr, hop_length=_hop(fps)).T

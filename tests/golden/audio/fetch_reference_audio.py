@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Copies the reference's own demo recordings — format fixtures it ships under demo_audio/ — into tests/golden/audio/ so that the
+GPU box (which has no /root/reference) can run the wav-in path on real speech: style.wav (22 kHz stereo int16, exactly 10.0 s),
+1st-page.wav (16 kHz mono, 12.816 s), french.wav (24 kHz mono, 9.6125 s).  Writes audio_manifest.json with their sha256, sample
+rate, shape and the frame counts SURVEY.md §8(c) documents for them (demo/*/*.npy hold 300 / 384 / 288 rows of 265 values).
+
+    python tests/golden/audio/fetch_reference_audio.py [/root/reference]
+"""
+import hashlib
+import json
+import os
+import shutil
+import sys
+
+from scipy.io import wavfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+FRAMES = {"style.wav": 300, "1st-page.wav": 384, "french.wav": 288}
+
+manifest = {}
+for name, frames in FRAMES.items():
+    src = os.path.join(REF, "demo_audio", name)
+    dst = os.path.join(HERE, name)
+    shutil.copyfile(src, dst)
+    os.chmod(dst, 0o644)
+    sr, a = wavfile.read(dst)
+    manifest[name] = {"sha256": hashlib.sha256(open(dst, "rb").read()).hexdigest(), "sample_rate": int(sr), "shape": list(a.shape),
+                      "dtype": str(a.dtype), "seconds": a.shape[0] / sr, "frames_30fps": frames,
+                      "source": "yhw-yhw/TalkSHOW demo_audio/" + name}
+json.dump(manifest, open(os.path.join(HERE, "audio_manifest.json"), "w"), indent=1)
+print(json.dumps(manifest, indent=1))

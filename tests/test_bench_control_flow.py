@@ -24,6 +24,7 @@ class StubJob:
     def __init__(self, world, rank, log):
         self.world, self.rank, self.log, self.steps_run = world, rank, log, []
         self.rows = None
+        self.fail_rank = -1
 
     def _say(self, what):
         with open(self.log, "a") as f:
@@ -60,6 +61,8 @@ class StubJob:
 
     def selfcheck(self):
         self._say("selfcheck")
+        if self.rank == self.fail_rank:
+            raise RuntimeError(f"selfcheck: rank {self.rank} found a difference")
         return {"selfcheck": "ok"}
 
     def extras(self, out):
@@ -115,3 +118,53 @@ def test_bench_contract_control_flow(tmp_path, world):
     assert ex["group_alive"] is False
     for r in range(1, world):
         assert outs[r]["end"] < outs[0]["end"] - 0.04, "a rank other than 0 was still around while rank 0 ran its extras"
+
+
+def _failing_worker(rank, world, port, tmp):
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    job = StubJob(world, rank, os.path.join(tmp, f"log{rank}.jsonl"))
+    job.fail_rank = 1
+    dt, _, info = bench.run_contract(job, dist, world, rank, 2, 1)
+    t0 = time.perf_counter()
+    try:
+        bench.finish(job, dist, world, rank, 2, 1, dt, info, emit=lambda line: None)
+        outcome = "returned"
+    except RuntimeError as e:
+        outcome = str(e)
+    with open(os.path.join(tmp, f"fail{rank}.json"), "w") as f:
+        json.dump({"outcome": outcome, "seconds": time.perf_counter() - t0, "group_alive": dist.is_initialized()}, f)
+
+
+def test_a_failed_selfcheck_does_not_strand_the_other_ranks(tmp_path):
+    """`finish` used to raise on the failing rank before the barrier, leaving the others in it until the RCCL time-out.
+    Now the failure is all-reduced, every rank leaves the process group, and every rank raises — at once."""
+    world = 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_failing_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [json.load(open(tmp_path / f"fail{r}.json")) for r in range(world)]
+    assert "rank 1 found a difference" in outs[1]["outcome"]
+    assert all("selfcheck failed on another rank" in outs[r]["outcome"] for r in (0, 2))
+    assert all(o["seconds"] < 20 and not o["group_alive"] for o in outs)
+
+
+def test_collectives_can_be_forced_at_world_one(tmp_path):
+    """TS_BENCH_FORCE_COLLECTIVES=1 (tools/rccl_smoke.sh): the N > 1 code path at world 1 — here on gloo."""
+    import bench
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        job = StubJob(1, 0, str(tmp_path / "log.jsonl"))
+        dt, _, info = bench.run_contract(job, dist, 1, 0, 3, 1, collectives=True)
+        lines = []
+        bench.finish(job, dist, 1, 0, 3, 1, dt, info, emit=lines.append, collectives=True)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    line = json.loads(lines[0])
+    assert line["rccl"]["ranks_seen"] == 1 and line["rccl"]["gathered_shape"] == [12, 3, 2] and line["n_gpus"] == 1
+    what = [json.loads(l)["what"] for l in open(tmp_path / "log.jsonl")]
+    assert what.count("gather") == 2

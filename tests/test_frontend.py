@@ -130,6 +130,38 @@ def test_whole_mfcc_against_third_party_pipeline():
     np.testing.assert_allclose(got, ref, atol=2e-2, rtol=1e-4)               # O(10..1000) coefficients, fp32 pipeline
 
 
+def test_mel_and_mel_mul_feature_types_pinned(tmp_path):
+    """`get_mfcc_ta(type='mel' | 'mel_mul')` (`data_utils/utils.py:178-191`: torchaudio MelSpectrogram; per-frame 1 s chunks, a 50 ms
+    window inside 2048-point frames, 10 ms hop, log) against the same pipelines assembled from installed third-party pieces:
+    torch.stft (what torchaudio's Spectrogram calls, incl. its centred short window) and transformers' HTK mel filter bank; the
+    chunking against the reference's own slicing rule written out."""
+    import torch
+    from scipy.io import wavfile
+    from transformers import audio_utils as au
+    sr = 22000
+    x = _wave(sr * 2 + 311, sr, seed=4)
+    path = str(tmp_path / "clip.wav")
+    wavfile.write(path, sr, x)
+    fb = au.mel_filter_bank(1025, 256, 0.0, float(sr // 2), sr, None, "htk")
+    mel = fe.get_mfcc_ta(path, sr=sr, fps=30, type="mel")
+    ref = _torch_stft_power(x, 2048, 734).astype(np.float64) @ fb
+    assert mel.shape == ref.shape == (len(x) // 734 + 1, 256)
+    np.testing.assert_allclose(mel, ref, rtol=2e-4, atol=2e-7 * float(ref.max()))
+    mm = fe.get_mfcc_ta(path, sr=sr, fps=30, type="mel_mul")
+    y = torch.from_numpy(np.float32(0.01) * x / np.mean(np.abs(x), dtype=np.float32))
+    spf, pad = sr // 30, (sr - sr // 30) // 2
+    yp = torch.nn.functional.pad(y[None], (pad, pad))[0]
+    chunks = torch.stack([yp[i - sr // 2:i + sr // 2] for i in range(sr // 2, yp.shape[0] - sr // 2, spf)])
+    spec = torch.stft(chunks, n_fft=2048, hop_length=sr // 100, win_length=sr // 20, window=torch.hann_window(sr // 20, periodic=True),
+                      center=True, pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+    refm = np.log(np.maximum(np.einsum("cft,fm->cmt", spec.abs().pow(2.0).numpy().astype(np.float64), fb), 1e-10))
+    assert mm.shape == refm.shape == (chunks.shape[0], 256, sr // (sr // 100) + 1)
+    big = refm > np.log(1e-9)                                  # away from the clamp, where a log amplifies fp32 noise without bound
+    np.testing.assert_allclose(mm[big], refm[big], atol=5e-3, rtol=0)
+    with pytest.raises(NotImplementedError, match="unknown feature type"):
+        fe.get_mfcc_ta(path, sr=sr, fps=30, type="chroma")
+
+
 # ---- librosa.load(sr=16000)'s resampler for the face path (resampy 'kaiser_best'; UNPINNED: librosa is not installed) ------
 def test_kaiser_best_table_against_closed_form():
     """The 32769-entry table == rolloff * sinc(rolloff t) * I0(beta sqrt(1 - (t/64)^2)) / I0(beta) evaluated directly."""

@@ -182,6 +182,70 @@ def test_demo_py_infer_against_the_drop_in(tmp_path, monkeypatch, stand):
     assert np.abs(arr[:300] - want).max() < 1e-4
 
 
+AUDIO = os.path.join(REPO, "tests", "golden", "audio")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["style.wav", "1st-page.wav", "french.wav"])
+def test_demo_py_on_the_reference_recordings(tmp_path, name):
+    """BASELINE configs[0] where the product runs: `scripts/demo.py::infer` (lifted, unchanged) on the reference's own demo recordings
+    (tests/golden/audio/, copied by fetch_reference_audio.py: 22 kHz stereo int16 / 16 kHz / 24 kHz mono) with NOTHING patched in the
+    audio path — wav file in, (T, 265) rows out: device resampler + MFCC -> audio encoder -> PixelCNN -> VQ decoders, device kaiser
+    resampler -> wav2vec2 face generator, `part2full`.  Checked: the frame counts the reference ships for these files
+    (`demo/style/*.npy` 300, `demo/1st-page/*.npy` 384, `demo/french/french.npy` 288 rows), the layout invariants of those shipped arrays
+    (columns 3:9 zero, 9:12 = the fixed global orientation, the lower-body joints = `lower_pose`), equality with the
+    oracle's assembly of the wrappers' own outputs, and the device MFCC rows against the float64 twin on real speech."""
+    import nets
+    from talkshow_amd import frontend as fe
+    from talkshow_amd.pose_index import lower_pose_block
+    units, _ = _units()
+    man = json.load(open(os.path.join(AUDIO, "audio_manifest.json")))[name]
+    wav_path = os.path.join(AUDIO, name)
+    T = man["frames_30fps"]
+    body_ckpt, face_ckpt = str(tmp_path / "body.pth"), str(tmp_path / "face.pth")
+    torch.save({"generator": {"generator": synth.to_torch(synth.pixelcnn_state_dict(seed=7)),
+                              "audioencoder": synth.to_torch(synth.audioencoder_state_dict(seed=7))}}, body_ckpt)
+    torch.save({"generator": {"generator": synth.to_torch(synth.face_state_dict(seed=7))}}, face_ckpt)
+    lb = {}
+    exec(units["lower_body"], lb)
+    rec = _SaveRecorder()
+    rendered = []
+    ns = dict(torch=torch, np=rec, s2g_face=nets.s2g_face, s2g_body_vq=nets.s2g_body_vq, s2g_body_pixel=nets.s2g_body_pixel,
+              LS3DCG=nets.LS3DCG, part2full=lb["part2full"],
+              Wav2Vec2Processor=types.SimpleNamespace(from_pretrained=lambda *a, **kw: "am-stub"),
+              get_vertices=lambda *a, **kw: (["verts"], None), matrix_to_axis_angle=None, rotation_6d_to_matrix=None)
+    exec(units["demo"], ns)
+    args = argparse.Namespace(gpu=0, infer=True, num_sample=1, audio_file=wav_path, id=2, only_face=False, stand=False, whole_body=False)
+    config = _config(tmp_path)
+    g_body = ns["init_model"]("s2g_body_pixel", body_ckpt, args, config)
+    g_face = ns["init_model"]("s2g_face", face_ckpt, args, config)
+    ns["infer"](_Greedy(g_body), g_face, None, types.SimpleNamespace(_render_sequences=lambda *a, **kw: rendered.append(a)), config, args)
+    assert len(rec.saved) == 1 and len(rendered) == 1
+    arr = rec.saved[0][1]
+    assert arr.shape == (T, 265) and arr.dtype == np.float32 and np.isfinite(arr).all()
+    # the wrappers alone: frame counts, and the saved rows are their outputs through the oracle's part2full restatement
+    poses = g_body.infer_on_audio(wav_path, id=torch.tensor([2]).cuda(), fps=30, greedy=True)
+    face = g_face.infer_on_audio(wav_path)
+    assert poses.shape == (1, T, 129) and face.shape == (1, T, 103)
+    want = O.assemble_full(poses, face, lower_pose_block(False))[0]
+    np.testing.assert_allclose(arr, want, atol=1e-6, rtol=0)
+    # layout invariants of the arrays the reference ships (demo/style/*.npy)
+    assert not arr[:, 3:9].any()                                                          # eye poses: never generated
+    np.testing.assert_allclose(arr[:, 9:12], np.tile(np.float32([3.0747, -0.0158, -0.0152]), (T, 1)), atol=1e-6, rtol=0)
+    lower = np.asarray(lower_pose_block(False), np.float32).reshape(-1)                   # `lower_pose` (lower_body.py:4-8), 33 values
+    cols = np.r_[3:18, 21:27, 30:36, 39:45]                                               # where part2full puts them (lower_body.py:77-86)
+    np.testing.assert_array_equal(arr[:, cols], np.tile(lower, (T, 1)))
+    assert arr[:, 165:].std() > 0 and arr[:, 0:3].std() > 0                               # expression / jaw do move
+    # the device front-end on real speech (stereo int16 -> mono, 22 k / 16 k / 24 k -> 22 k): MFCC rows vs the float64 twin
+    dev_rows = fe.get_mfcc_ta(wav_path, sr=22000, fps=30, smlpx=True, type="mfcc")
+    wave = fe._load_mono_resampled(wav_path, 22000)
+    twin = fe.mfcc_float64(wave, 22000, hop_length=734).T
+    assert dev_rows.shape == twin.shape and abs(dev_rows.shape[0] - (T + 1)) <= 1
+    err = float(np.abs(dev_rows - twin).max())
+    print(f"\n{name}: device MFCC vs float64 twin max |err| = {err:.2e} over coefficients up to {np.abs(twin).max():.0f}")
+    assert err <= 5e-4
+
+
 class _SMPLXStandIn:
     """`smplx.create(...)` stand-in with the call shape `data_utils/get_j.py` uses: keyword groups in, {'joints': (N, J, 3)} out,
     on this repo's device SMPL-X layer over synthetic model parameters (the licensed model file is absent: SURVEY.md §8f-2)."""
