@@ -132,7 +132,9 @@ typedef struct ts_pixelcnn_v ts_pixelcnn_v;
 int ts_pixelcnn_v_create(ts_ctx *ctx, const ts_tensor *sd, int n, int input_dim, int dim, int n_layers, int n_classes, int audio,
                          int aud_dim, ts_pixelcnn_v **out);
 void ts_pixelcnn_v_destroy(ts_pixelcnn_v *pix);
-/* generate / forward of that form: label_dev (B,), aud_dev (B,H,aud_dim) or NULL (audio == 0), grid (H, W) with W a power of two;
+/* generate / forward of that form: label_dev (B,), aud_dev (B,H,aud_dim) or NULL (audio == 0) — ONE audio row per code row: the
+ * reference's (B, aud_dim, H, W) map with all W columns equal, as its caller builds it (smplx_body_pixel.py:274); a map whose columns
+ * differ has no counterpart here (the Python layer raises NotImplementedError instead of dropping columns) —, grid (H, W) with W a power of two;
  * codes_dev (B,H,W) int64 out (in for TS_TEACHER_FORCED), logits_dev optional (B,H,W,input_dim), uniforms_dev (B,H,W) for
  * TS_SAMPLE_UNIFORMS; Philox position of (row, column) = (H0 + row) * W + column; prefix as in ts_pixelcnn_generate
  * (pre_codes_dev (B,H0,W), pre_aud_dev (B,H0,aud_dim)). */

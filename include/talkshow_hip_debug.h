@@ -48,6 +48,10 @@ int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin,
                        const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
                        void *stream);
 
+/* Test aid: out[i] = the chain kernels' gate activation tanh(v[i]) * sigmoid(p[i]) as they compute it (v_exp_f32 / v_rcp_f32 form,
+ * csrc/kernels.h::gate_act; reference: GatedActivation, gated_pixelcnn_v2.py:16-22) on n device floats. */
+int ts_debug_gate_act(const float *v_dev, const float *p_dev, float *out_dev, long n, void *stream);
+
 /* Test aid: how many captured hipGraphs the PixelCNN keeps for `stream` right now (whole-call graphs of repeated shapes + the chunk
  * graphs that serve first-time shapes of any length; bounded, least recently used out first), or -1. */
 int ts_debug_pixelcnn_graphs(ts_pixelcnn *pix, void *stream);

@@ -51,7 +51,10 @@ def lift(path, names):
         src = open(path, encoding="utf-8").read()
     except OSError as e:
         raise RefCallersError(f"cannot read {path}: {e}")
-    tree = ast.parse(src, filename=path)
+    try:
+        tree = ast.parse(src, filename=path)
+    except (SyntaxError, ValueError) as e:      # a reference file this interpreter cannot parse costs the caller tests, not the build
+        raise RefCallersError(f"cannot parse {path}: {e}")
     if names is not None:
         keep = []
         for node in tree.body:
@@ -66,7 +69,10 @@ def lift(path, names):
             raise RefCallersError(f"{path}: not found: {missing} (the reference's layout changed?)")
         tree = ast.Module(body=keep, type_ignores=[])
     rel = os.path.relpath(path, REF)
-    return compile(tree, f"<reference {rel}>", "exec"), _sha(src.encode())
+    try:
+        return compile(tree, f"<reference {rel}>", "exec"), _sha(src.encode())
+    except (SyntaxError, ValueError, TypeError) as e:
+        raise RefCallersError(f"cannot compile the lifted part of {path}: {e}")
 
 
 def build(out_dir=OUT_DIR):
@@ -97,11 +103,16 @@ def load(out_dir=OUT_DIR):
 
     Every `.code` file must hash to what the manifest says (and, where the reference tree is present, every reference file
     to the hash it had when lifted) before a single byte of it is unmarshalled: a file that fails raises RefCallersError, it is
-    never executed.  The unit set and file names are fixed by UNITS above, not by the manifest."""
+    never executed.  This is a CORRUPTION / STALENESS check, not a defence against tampering — the manifest sits beside the files
+    it describes, whoever can rewrite one can rewrite the other; the code objects are test infrastructure built from the local
+    reference tree and executed by tests only.  The unit set and file names are fixed by UNITS above, not by the manifest."""
     path = os.path.join(out_dir, "reference_callers.json")
     if not os.path.exists(path):
         return None
-    m = json.load(open(path))
+    try:
+        m = json.load(open(path))
+    except (OSError, ValueError) as e:
+        raise RefCallersError(f"{path} is unreadable: {e}")
     if list(sys.version_info[:2]) != m.get("python"):
         return None
     units = {}
@@ -118,7 +129,10 @@ def load(out_dir=OUT_DIR):
         ref_file = os.path.join(REF, rel)
         if os.path.exists(ref_file) and _sha(open(ref_file, "rb").read()) != ent.get("source_sha256"):
             raise RefCallersError(f"{rel} changed since the callers were lifted: rebuild (python oracle/build_ref_callers.py)")
-        units[unit] = marshal.loads(blob)
+        try:
+            units[unit] = marshal.loads(blob)
+        except (EOFError, ValueError, TypeError) as e:
+            raise RefCallersError(f"{unit}.code does not unmarshal: {e}")
     return units, m
 
 

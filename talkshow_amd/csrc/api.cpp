@@ -234,6 +234,12 @@ int ts_op_conv1d_timed(ts_ctx *ctx, const float *x, int B, int Lin, int Cin, con
     return 0;
 }
 
+int ts_debug_gate_act(const float *v_dev, const float *p_dev, float *out_dev, long n, void *stream) {
+    if (!v_dev || !p_dev || !out_dev || n < 0) return fail("ts_debug_gate_act: bad argument");
+    TS_HIP(ts::launch_gate_act(v_dev, p_dev, out_dev, n, (hipStream_t)stream));
+    return 0;
+}
+
 int ts_op_vq_argmin(ts_ctx *ctx, const float *x, int M, const float *cb, int ncode, int dim, int64_t *idx, void *stream) {
     if (!ctx || !x || !cb || !idx) return fail("ts_op_vq_argmin: null argument");
     hipStream_t s = (hipStream_t)stream;

@@ -238,8 +238,11 @@ void ts_face_destroy(ts_face *f) { delete f; }
 int ts_face_set_arith(ts_face *f, int bf16_products) {
     if (!f) return fail("ts_face_set_arith: null argument");
     if (bf16_products != 0 && bf16_products != 3 && bf16_products != 6) return fail("ts_face_set_arith: 0 (fp32), 3 or 6 bf16 products");
-    f->split_planes = bf16_products == 0 ? 0 : (bf16_products == 3 ? 2 : 3);
-    if (f->split_planes == 2 && !f->pos_wp.p) {
+    const int planes = bf16_products == 0 ? 0 : (bf16_products == 3 ? 2 : 3);
+    // (the plan is published LAST, after the weight plane images exist and the device has finished writing them: a generate call that
+    // starts after this function returns sees a complete plan.  Like every entry of a handle, set_arith must not run concurrently
+    // with ts_face_generate on the same handle — talkshow_hip.h, thread contract.)
+    if (planes == 2 && !f->pos_wp.p) {
         // weights are constants: their two bf16 planes are made once, here, in the layout conv_gemm_split copies into LDS, and only the
         // activations are split per call (the plane images have the size and pitch of the fp32 matrices: + 1 x the weights of HBM)
         TS_HIP(hipSetDevice(f->ctx->device));
@@ -261,8 +264,9 @@ int ts_face_set_arith(ts_face *f, int bf16_products) {
         }
         TS_TRY(f->pos_wp.ensure(f->pos_w.bytes));
         TS_HIP(launch_split_weight_planes(f->pos_w.f(), f->pos_wp.f(), (long)(f->pos_w.bytes / sizeof(float) / f->pos_ktot), f->pos_ktot, nullptr));
-        TS_HIP(hipStreamSynchronize(nullptr));
+        TS_HIP(hipDeviceSynchronize());   // the fills ran on the null stream; generate streams are non-blocking: order by completion
     }
+    f->split_planes = planes;
     return 0;
 }
 

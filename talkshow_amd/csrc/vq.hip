@@ -234,6 +234,16 @@ hipError_t launch_set_words3(uint64_t *dst, uint64_t a, uint64_t b, uint64_t c, 
     return hipGetLastError();
 }
 
+// test aid: out[i] = gate_act(v[i], p[i]) — the chain kernels' gate on given operands (tests measure it against tanh * sigmoid in float64)
+__global__ void gate_act_kernel(const float *v, const float *p, float *out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gate_act(v[i], p[i]);
+}
+hipError_t launch_gate_act(const float *v, const float *p, float *out, long n, hipStream_t stream) {
+    hipLaunchKernelGGL(gate_act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, v, p, out, n);
+    return hipGetLastError();
+}
+
 // measurement aid: one wave that sleeps and, every `window_ticks` of the 100 MHz wall clock, records (wall ticks, shader cycles)
 // since the previous record — the shader clock the chip actually runs at while other streams load it
 __global__ void clock_sample_kernel(unsigned long long *out, int n, unsigned long long window_ticks) {

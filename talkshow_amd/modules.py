@@ -397,6 +397,19 @@ class GatedPixelCNN(NativeModule):
             raise NotImplementedError("streaming sessions exist for the shipped configuration (audio=True, bh_model=True)")
         return PixelCNNStream(self, label, batch_size, max_chunk_rows)
 
+    @staticmethod
+    def _audio_rows(aud):
+        """(B, aud_dim, H, W) audio map of the reference call shape -> the (B, H, aud_dim) rows the C entry takes (ONE audio row per
+        code row).  The reference convolves the whole map; its only caller builds it by repeating one row over the columns
+        (`smplx_body_pixel.py:274`), and that is the case implemented: a map whose columns differ is refused, not silently
+        truncated to its first column."""
+        if aud is None:
+            return None
+        if aud.shape[-1] > 1 and not bool((aud == aud[..., :1]).all()):
+            raise NotImplementedError("GatedPixelCNN: the audio map's columns differ; one audio row per code row is supported "
+                                      "(the reference's caller repeats a row over the columns, smplx_body_pixel.py:274)")
+        return aud[..., 0].transpose(1, 2)
+
     # --- reference call shapes ---
     def generate(self, label, shape=(8, 8), batch_size=64, aud_feat=None, pre_latents=None, pre_audio=None,
                  mode=None, seed=None, uniforms=None):
@@ -405,8 +418,8 @@ class GatedPixelCNN(NativeModule):
         Default is stochastic like the reference (softmax + one multinomial draw per position), with Philox uniforms
         seeded from torch's default generator; `mode=TS_SAMPLE_GREEDY` gives the argmax harness.
         """
-        rows = aud_feat[..., 0].transpose(1, 2) if aud_feat is not None else None      # the columns are copies (smplx_body_pixel.py:274)
-        pre_rows = pre_audio[..., 0].transpose(1, 2) if pre_audio is not None else None
+        rows = self._audio_rows(aud_feat)
+        pre_rows = self._audio_rows(pre_audio)
         if mode is None:
             mode = _lib.TS_SAMPLE_PHILOX if uniforms is None else _lib.TS_SAMPLE_UNIFORMS
         if seed is None:
@@ -417,7 +430,7 @@ class GatedPixelCNN(NativeModule):
 
     def __call__(self, x, label, aud=None):
         """`GatedPixelCNN.forward` (`gated_pixelcnn_v2.py:130-150`): x (B,H,2) codes -> logits (B,input_dim,H,2)."""
-        rows = aud[..., 0].transpose(1, 2) if aud is not None else None
+        rows = self._audio_rows(aud)
         _, logits = self.run(label, rows, mode=_lib.TS_TEACHER_FORCED, codes=x, want_logits=True, shape=tuple(x.shape))
         return logits.permute(0, 3, 1, 2)
 

@@ -133,6 +133,33 @@ def test_conv_banded_launch_matches_plain_tiles(hip):
     np.testing.assert_allclose(outs[0][:, rows, :], ref, atol=2e-5, rtol=1e-5)
 
 
+def test_gate_activation_accuracy(hip):
+    """The chain kernels' gate — tanh(v) * sigmoid(p) on v_exp_f32 / v_rcp_f32 (`kernels.h::gate_act`; reference `GatedActivation`,
+    `gated_pixelcnn_v2.py:16-22`: torch.tanh * torch.sigmoid) — against float64 over the whole input range, tiny |v| and saturation
+    included: the ABSOLUTE error, which is what the next layer's O(1) sums see, stays under 3e-7; the relative error of
+    the tanh factor near v = 0 (the formula cancels there) is recorded."""
+    _lib, lib, _ = hip
+    rng = np.random.default_rng(3)
+    v = np.concatenate([rng.uniform(-12, 12, 200000), rng.uniform(-1, 1, 100000) * 10.0 ** rng.uniform(-6, 0, 100000),
+                        np.float64([0.0, -0.0, 1e-8, -1e-8, 30.0, -30.0, 88.0, -88.0, 1e4, -1e4])]).astype(np.float32)
+    p = np.concatenate([rng.uniform(-12, 12, 300000), np.float64([0.0, 5.0, -5.0, 30.0, -30.0, 88.0, -88.0, 1e4, -1e4, 0.5])]).astype(np.float32)
+    vd, pd = dev(v), dev(p)
+    out = torch.empty_like(vd)
+    _lib.check(lib.ts_debug_gate_act(_lib.dptr(vd), _lib.dptr(pd), _lib.dptr(out), v.size, None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.float64)
+    v64, p64 = v.astype(np.float64), p.astype(np.float64)
+    ref = np.tanh(v64) / (1.0 + np.exp(-np.clip(p64, -700, 700)))
+    assert np.isfinite(got).all()
+    assert_close_measured("gate_act.abs", got, ref, 3e-7)
+    small = (np.abs(v64) > 0) & (np.abs(v64) < 1e-2) & (p64 > -2)
+    rel = np.abs(got[small] - ref[small]) / np.abs(ref[small])
+    print(f"gate_act: relative error of tanh(v) * sigmoid(p) for |v| < 1e-2: median {np.median(rel):.1e}, max {rel.max():.1e} "
+          f"(max |v| * rel = {float((np.abs(v64[small]) * rel).max()):.1e})")
+    assert float((np.abs(v64[small]) * rel).max()) < 3e-7            # the relative error IS the absolute one over |tanh v| ~ |v|
+    assert got[-10] == 0.0 and got[-9] == 0.0                          # tanh(+-0) * sigmoid = 0 exactly
+
+
 def test_clock_sampler_reports_a_plausible_shader_clock(hip):
     """ts_debug_clock_sample (tools/conv_clock.py): shader cycles per 100 MHz wall-clock window on an idle device must come out
     between 1 and 2.6 GHz (MI355X: 2.4 GHz nominal), window lengths at the requested 200 us."""

@@ -301,3 +301,18 @@ def test_index_range_check_has_no_stale_hits():
     for bad in ([0, -1], np.array([5]), 7, torch.tensor([[1, 9]])):
         with pytest.raises(IndexError):
             _check_index_range(bad, 4, "label")
+
+
+def test_pixelcnn_audio_map_columns_must_be_copies():
+    """the reference convolves the whole (B, aud_dim, H, W) audio map; the C entries take one audio row per code row (its only
+    caller repeats a row over the columns, `smplx_body_pixel.py:274`).  A map whose columns differ is refused, not cut to column 0."""
+    import torch
+    from talkshow_amd.modules import GatedPixelCNN
+    rows = torch.randn(2, 8, 5)
+    same = rows[..., None].repeat(1, 1, 1, 4)
+    assert torch.equal(GatedPixelCNN._audio_rows(same), rows.transpose(1, 2))
+    assert GatedPixelCNN._audio_rows(None) is None
+    other = same.clone()
+    other[1, 3, 2, 3] += 1.0
+    with pytest.raises(NotImplementedError, match="columns differ"):
+        GatedPixelCNN._audio_rows(other)
