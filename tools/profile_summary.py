@@ -14,7 +14,7 @@ from collections import defaultdict
 def family(name):
     if "skinny" in name:
         return "skinny_gemm_f32"
-    if "conv_gemm_kernel" in name:
+    if "conv_gemm_kernel" in name or "conv_gemm_banded_kernel" in name or "conv_ring_kernel" in name:
         return "conv_gemm_f32"
     m = re.match(r"(?:void )?(?:ts::)?([A-Za-z0-9_]+)", name)
     return m.group(1) if m else name[:40]
