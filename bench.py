@@ -160,6 +160,29 @@ def face_block(local):
            "attention_fused": {"launches": nf[3], "ms": msf[3], "achieved_TFLOPs": ach_a, "frac_of_fp32_mfma_peak": ach_a / PEAK_FP32_MFMA_TFLOPS,
                                "what": "QK^T -> online soft-max -> PV per (clip, head) in one kernel (csrc/face.hip::attention_kernel), 12 layers"},
            "other_kernels_ms": msf[2]}
+    # two batches of 64 in flight on two streams (one weight copy, scratch per stream): what a serving loop gains from filling one
+    # batch's partly filled GEMM rounds and launch gaps with the other's workgroups; each batch's rows are the one-stream rows
+    try:
+        streams = _lib.create_streams(2, local)
+        sets = [(wav, ids), (torch.from_numpy(synth.wav16(3001, B, N)).cuda(), ids)]
+        res = [None, None]
+
+        def both():
+            for i, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    res[i] = m.run(sets[i][0], sets[i][1], T)
+        ref0 = m.run(wav, ids, T)
+        both()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(res[0], ref0))
+        t0 = time.perf_counter()
+        for _ in range(K):
+            both()
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / K / 2
+        out["two_batches_in_flight"] = {"ms_per_batch": dt2 * 1e3, "frames_per_s": B * T / dt2, "rows_equal_one_stream": same}
+    except Exception as e:                                   # extra information; never lose the block
+        out["two_batches_in_flight"] = {"error": repr(e)}
     # OPT-IN split-bf16 plans beside the fp32 line (never the headline; dtype of the main line stays f32): speed on the same batch,
     # error of the same two reference-golden clips the parity tests use (tests/golden/face_10s.npz), embedded in a batch of 64
     try:

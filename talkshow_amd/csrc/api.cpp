@@ -26,6 +26,7 @@ const Knobs &knobs() {
         auto num = [](const char *name, int dflt) { const char *e = std::getenv(name); return e && e[0] ? std::atoi(e) : dflt; };
         v.conv_bands = num("TS_CONV_BANDS", 1) != 0;
         v.conv_ring = num("TS_CONV_RING", 9);
+        v.vq_lds = num("TS_VQ_LDS", 1) != 0;
         v.split_xcd = num("TS_SPLIT_XCD", 8);
         v.prof_log = num("TS_PROF_LOG", 0) != 0;
         if (const char *e = std::getenv("TS_NO_GRAPH")) v.no_graph = e[0] && e[0] != '0';

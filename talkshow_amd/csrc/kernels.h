@@ -201,6 +201,7 @@ hipError_t launch_clock_sample(unsigned long long *out, int n, unsigned long lon
 // ------------------------------------------------------------------------------------------------
 struct Knobs {
     bool conv_bands = true;     // TS_CONV_BANDS=0: big conv layers as one plain grid of 128 x 128 tiles
+    bool vq_lds = true;         // TS_VQ_LDS=0: the codebook search reads code rows from L2 per thread instead of LDS-staged tiles (tests, A/B)
     int conv_ring = 9;          // TS_CONV_RING=0|1|9: single-problem layers that take 128 x 128 tiles on conv_gemm.hip / the ring engine with 4 / 8 waves (conv_gemm_ring.hip)
     int split_xcd = 8;          // TS_SPLIT_XCD: column-group width of conv_gemm_split's XCD-aware tile order (0: plain 2-D tile grid)
     bool prof_log = false;      // TS_PROF_LOG=1: one stderr line per conv launch while ts_prof is enabled

@@ -99,9 +99,112 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// vq_argmin, LDS-staged form (dim = 64: the VQ-VAE's embedding width).  The kernel above lets every thread pull its own code
+// rows from L2 — a wave load touches 64 rows x 16 B, and a workgroup of 8 query rows reads the whole 512 KB codebook.  Here:
+//   * a workgroup serves 4 x RW query rows and walks the codebook in TILES of 64 codes, staged through LDS by coalesced 16-byte
+//     loads (a tile is 16 KB contiguous) into rows pitched 68 floats — lane l then reads code l of the tile with ds_read_b128,
+//     conflict-free — and double-buffered: tile t + 1 is on its way while tile t is multiplied;
+//   * lane = code, wave = RW query rows: the query values are WAVE-UNIFORM, so they come through the scalar unit (s_load) and
+//     enter the FMAs as scalar operands — no LDS traffic, no broadcast, 64 v_fmac per (row, tile) against the lane's 64 code
+//     registers;
+//   * a lane keeps its running (distance, index) per row over the tiles it sees (codes l, l + 64, ...: ascending, strict '<'
+//     keeps the lowest index), one wavefront reduction per row at the end (ties -> lowest index).
+// Same arithmetic as above, operation for operation — dot as the c-ascending fmaf chain, (|x|^2 + |e|^2) - 2 dot, |x|^2 summed
+// in c order — so the two kernels return the same index for every row (tests/test_gpu_parity.py::test_vq_argmin_lds_form).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int VQ_TILE = 64, VQ_DIM = 64, VQ_PITCH = VQ_DIM + 4;
+
+template <int RW>
+__global__ __launch_bounds__(256) void vq_argmin_lds_kernel(const float *__restrict__ x, int ldx, int M, const float *__restrict__ cb,
+                                                            const float *__restrict__ csq, int ncode, int64_t *__restrict__ idx, long idx_stride) {
+    __shared__ __attribute__((aligned(16))) float tile[2][VQ_TILE][VQ_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * (4 * RW) + wave * RW;   // this wave's first query row (wave-uniform)
+    const int ntile = (ncode + VQ_TILE - 1) / VQ_TILE;
+
+    // |x|^2 of the wave's rows, in the order the kernel above sums it (wave-uniform values: every lane computes the same number)
+    float xsq[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const float *xr = x + (long)(m0 + r < M ? m0 + r : 0) * ldx;
+        float sq = 0.f;
+        for (int c = 0; c < VQ_DIM; ++c) sq += xr[c] * xr[c];
+        xsq[r] = sq;
+    }
+    float best[RW];
+    int bidx[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) { best[r] = INFINITY; bidx[r] = 0x7fffffff; }
+
+    // staging: a tile is 64 x 64 floats = 1024 16-byte chunks, 4 per thread; chunk q -> row q / 16, columns 4 (q % 16) ..
+    f32x4 st[4];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i, row = q >> 4;
+            st[i] = t * VQ_TILE + row < ncode ? *reinterpret_cast<const f32x4 *>(cb + ((long)t * VQ_TILE + row) * VQ_DIM + (q & 15) * 4)
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i;
+            *reinterpret_cast<f32x4 *>(&tile[buf][q >> 4][(q & 15) * 4]) = st[i];
+        }
+    };
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntile) fetch(t + 1);   // in flight under this tile's FMAs
+        f32x4 e[VQ_DIM / 4];
+#pragma unroll
+        for (int c4 = 0; c4 < VQ_DIM / 4; ++c4) e[c4] = *reinterpret_cast<const f32x4 *>(&tile[buf][lane][c4 * 4]);
+        const int j = t * VQ_TILE + lane;
+        const float ee = j < ncode ? csq[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const float *xr = x + (long)(m0 + r < M ? m0 + r : 0) * ldx;   // wave-uniform address: scalar loads
+            float dot = 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < VQ_DIM / 4; ++c4) {
+                dot = fmaf(xr[c4 * 4 + 0], e[c4][0], dot);
+                dot = fmaf(xr[c4 * 4 + 1], e[c4][1], dot);
+                dot = fmaf(xr[c4 * 4 + 2], e[c4][2], dot);
+                dot = fmaf(xr[c4 * 4 + 3], e[c4][3], dot);
+            }
+            const float d = (xsq[r] + ee) - 2.0f * dot;
+            if (j < ncode && d < best[r]) { best[r] = d; bidx[r] = j; }
+        }
+        if (t + 1 < ntile) park(buf ^ 1);   // the other buffer was last read two iterations ago, behind the barrier below
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        float d = best[r];
+        int j = bidx[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(d, off);
+            const int oj = __shfl_xor(j, off);
+            if (od < d || (od == d && oj < j)) { d = od; j = oj; }
+        }
+        if (lane == 0 && m0 + r < M) idx[(long)(m0 + r) * idx_stride] = j;
+    }
+}
+
 hipError_t launch_vq_argmin(const float *x, int ldx, int M, const float *codebook, const float *code_sq, int ncode,
                             int dim, int64_t *idx, long idx_stride, hipStream_t stream) {
     if (dim % 4 != 0) return hipErrorInvalidValue;
+    if (dim == VQ_DIM && knobs().vq_lds && (reinterpret_cast<uintptr_t>(codebook) & 15) == 0) {
+        // 32 rows per workgroup once that still fills the chip, else 8 (the batch-of-32 call: 2 400 rows)
+        if (M >= 32 * 512) hipLaunchKernelGGL(vq_argmin_lds_kernel<8>, dim3((M + 31) / 32), dim3(256), 0, stream, x, ldx, M, codebook, code_sq, ncode, idx, idx_stride);
+        else hipLaunchKernelGGL(vq_argmin_lds_kernel<2>, dim3((M + 7) / 8), dim3(256), 0, stream, x, ldx, M, codebook, code_sq, ncode, idx, idx_stride);
+        return hipGetLastError();
+    }
     size_t smem = (VQ_ROWS * dim + VQ_ROWS + 4 * VQ_ROWS) * sizeof(float) + 4 * VQ_ROWS * sizeof(int);
     hipLaunchKernelGGL(vq_argmin_kernel, dim3((M + VQ_ROWS - 1) / VQ_ROWS), dim3(256), smem, stream, x, ldx, M,
                        codebook, code_sq, ncode, dim, idx, idx_stride);

@@ -180,7 +180,9 @@ def _fma32(a, b, c):
     return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
 
 
-@pytest.mark.parametrize("M,ncode,dim", [(1, 128, 64), (13, 2048, 64), (2400, 2048, 64)])
+# dim 64: the LDS-staged form (csrc/vq.hip::vq_argmin_lds_kernel: 8 rows per workgroup below 16 384 rows, 32 from there on; a codebook
+# that is not a multiple of the 64-code tile; rows that do not fill the last workgroup); dim 32: the per-thread form
+@pytest.mark.parametrize("M,ncode,dim", [(1, 128, 64), (13, 2048, 64), (2400, 2048, 64), (19200, 2048, 64), (16397, 200, 64), (45, 96, 32)])
 def test_op_vq_argmin(hip, M, ncode, dim):
     """Index work is bit-exact: (a) on operands whose every product and partial sum is exactly representable in fp32 (multiples
     of 1/64 in [-4, 4]) the distances are exact whatever the summation order, so the indices must equal numpy's float64 argmin,
@@ -1054,22 +1056,24 @@ def test_wav_in_code_stability(hip, tmp_path):
                                  {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"},
                                  {"TS_SKINNY_TILED": "0", "TS_WITH_CLIPS": "1"}, {"TS_PIX_DEFER_P": "0", "TS_WITH_CLIPS": "1"},
                                  {"TS_PIX_DEFER_P": "1", "TS_WITH_CLIPS": "1"}, {"TS_SKINNY_WIDE_MIN": "0", "TS_WITH_CLIPS": "1"},
-                                 {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}],
+                                 {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}, {"TS_VQ_LDS": "0", "TS_CONV_RING": "0", "TS_WITH_VQ": "1"}],
                          ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
                               "row_major_operands", "projections_in_column0", "projections_in_column1",
-                              "split_k_kernels_only", "wide_kernel_everywhere"])
+                              "split_k_kernels_only", "wide_kernel_everywhere", "per_thread_vq_search_and_register_staged_conv"])
 def test_alternate_kernel_paths(hip, env):
     """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
     launches, the 32-column kernel), row-major instead of tiled operands, two placements of the next-row projections, and
     the 64 x 64 wide kernel that coalesced passes use for launches of >= 160 workgroups (forced off / forced onto every
-    launch of >= 64 clips here, small head / column-1 launches included).  The knobs are read once per process, so the
+    launch of >= 64 clips here, small head / column-1 launches included); the codebook search has an LDS-staged and a per-thread
+    form, conv_gemm_f32 a register-staged and an LDS-DMA engine (the last entry forces the older of each).  The knobs are read once per process, so the
     golden-vector tests are re-run in a child process with each path forced: all must stay bit-exact on the codes."""
     import subprocess
     import sys
     child_env = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q",
                         "-k", "pixelcnn_golden or pixelcnn_sampling_and_prefix or single_layer_pixelcnn or op_linear"
-                        + (" or golden_clips" if env.get("TS_WITH_CLIPS") else "")],   # BASELINE-size batches: the coalesced tile shapes
+                        + (" or golden_clips" if env.get("TS_WITH_CLIPS") else "")     # BASELINE-size batches: the coalesced tile shapes
+                        + (" or op_vq_argmin or vqvae_golden or wrapper_body_vq or face_golden" if env.get("TS_WITH_VQ") else "")],
                        env=child_env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
