@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Copies the reference's own demo recordings — format fixtures it ships under demo_audio/ — into tests/golden/audio/ so that the
-GPU box (which has no /root/reference) can run the wav-in path on real speech: style.wav (22 kHz stereo int16, exactly 10.0 s),
+"""Copies the reference's own demo recordings — format fixtures it ships under demo_audio/ — into tests/golden/audio/ (git-ignored:
+they are the reference's files, not this repository's; `__graft_entry__.build()` runs this where /root/reference exists and the
+copies travel to the GPU box with the snapshot, like oracle/_ref) so that the GPU box, which has no /root/reference, can run the
+wav-in path on real speech: style.wav (22 kHz stereo int16, exactly 10.0 s),
 1st-page.wav (16 kHz mono, 12.816 s), french.wav (24 kHz mono, 9.6125 s).  Writes audio_manifest.json with their sha256, sample
 rate, shape and the frame counts SURVEY.md §8(c) documents for them (demo/*/*.npy hold 300 / 384 / 288 rows of 265 values).
 
