@@ -42,11 +42,16 @@ int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int g
 /* Tuning / roofline entry (not part of the drop-in surface): a stride-1 conv layer (K = 1 or 3, Cin % 32 == 0)
  * whose weights are ALREADY packed on the device as [round128(Cout)][K*Cin] (tap-major, k contiguous), launched
  * `iters` times between two HIP events recorded on `stream`; tile: 0 = production heuristic, 1 = 128x128,
- * 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 with 64-deep K chunks, 6 = 160x128, 7 = 96x128; 31 / 39 = the LDS-DMA ring engine's
- * 128x128 tile with 4 / 8 waves (conv_gemm_ring.hip).  *ms_out = mean launch duration in milliseconds. */
+ * 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 with 64-deep K chunks, 6 = 160x128, 7 = 96x128; 31 / 39 / 33 = the LDS-DMA ring engine's
+ * 128x128 tile with 4 / 8 waves and its 96x128 tile (conv_gemm_ring.hip).  *ms_out = mean launch duration in milliseconds. */
 int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
                        const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
                        void *stream);
+
+/* Host-only helper (no GPU needed): the tile height (128 or 96 rows, 128 columns) conv_gemm_f32's LDS-DMA ring engine gives a single-problem
+ * layer of M rows x N columns — by tile count: rounds of 512 resident workgroups, a last round at most half full costs half a round
+ * (csrc/conv_gemm_ring.hip::conv_gemm_ring_pick).  -1 on a bad argument.  No reference counterpart. */
+int ts_debug_conv_ring_pick(int M, int N, int groups);
 
 /* Test aid: out[i] = the chain kernels' gate activation tanh(v[i]) * sigmoid(p[i]) as they compute it (v_exp_f32 / v_rcp_f32 form,
  * csrc/kernels.h::gate_act; reference: GatedActivation, gated_pixelcnn_v2.py:16-22) on n device floats. */

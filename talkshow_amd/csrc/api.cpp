@@ -235,6 +235,16 @@ int ts_op_conv1d_timed(ts_ctx *ctx, const float *x, int B, int Lin, int Cin, con
     return 0;
 }
 
+int ts_debug_conv_ring_pick(int M, int N, int groups) {
+    if (M < 1 || N < 1 || groups < 1 || groups > 4) return -1;
+    ts::ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.M = M;
+    p.N = N;
+    p.ngroups = groups;
+    return ts::conv_gemm_ring_pick(p) == 3 ? 96 : 128;
+}
+
 int ts_debug_gate_act(const float *v_dev, const float *p_dev, float *out_dev, long n, void *stream) {
     if (!v_dev || !p_dev || !out_dev || n < 0) return fail("ts_debug_gate_act: bad argument");
     TS_HIP(ts::launch_gate_act(v_dev, p_dev, out_dev, n, (hipStream_t)stream));

@@ -252,6 +252,24 @@ bool conv_gemm_ring_takes(const ConvParams &p) {
     return true;
 }
 
+// Which tile for a single-problem layer?  A launch is rounds of 512 resident workgroups (two per CU); a workgroup alone on its CU
+// runs at the full pipe rate (tools/ring_probe.py: 256 tiles on 256 CUs take what 512 take), so a last round that is at most half
+// full costs half a round, a fuller one a whole round.  128 x 128 tiles on 8 waves are the fastest per tile; 96 x 128 tiles (4 waves
+// of 96 x 32, ~5 % slower per flop) change the tile COUNT: the N = 768 layers of the wav2vec2 blocks (900 tiles of 128 rows = 1.76
+// rounds -> 2; 1 200 of 96 rows = 2.34 rounds -> 2.5 x 0.75 = 1.875) take them — out-proj 207 -> 200 us, FFN2 750 -> 718 us inside a
+// face batch —, FFN1 (7.03 -> 7.5; 9.375 -> 9.5 x 0.75 = 7.125: a tie once the 5 % are counted) and QKV (5.27 -> 5.5 against 7.03 ->
+// 7.5 x 0.75 = 5.625) do not.  Measured: profiles/r05_notes/ring_tall_tiles.txt, face_layers_ab.txt.
+int conv_gemm_ring_pick(const ConvParams &p) {
+    const long nt = (long)((p.N + 127) / 128) * p.ngroups;
+    auto cost = [&](int bm, double eff) {
+        const long tiles = (long)((p.M + bm - 1) / bm) * nt;
+        const long full = tiles / 512, rest = tiles - full * 512;
+        const double rounds = (double)full + (rest == 0 ? 0.0 : (rest <= 256 ? 0.5 : 1.0));
+        return rounds * bm / eff;
+    };
+    return cost(96, 0.95) < cost(128, 1.0) ? 3 : 9;   // a 96 x 128 tile runs ~5 % below the 8-wave 128 x 128 tile per flop (layers without a tail: 122.7 vs 130.8, 114 vs 123 TFLOP/s)
+}
+
 hipError_t launch_conv_gemm_ring(const ConvParams &p_in, int variant, hipStream_t stream) {
     ConvParams p = p_in;
     if (!p.zero) {
@@ -259,10 +277,12 @@ hipError_t launch_conv_gemm_ring(const ConvParams &p_in, int variant, hipStream_
         if (hipGetDevice(&dev) == hipSuccess) p.zero = skinny_zero_buffer(dev);
     }
     if (!p.zero || !conv_gemm_ring_takes(p)) return hipErrorInvalidValue;
+    if (variant == 0) variant = conv_gemm_ring_pick(p);
     const dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.ngroups);
     switch (variant) {
         case 1: hipLaunchKernelGGL((conv_ring_kernel<128, 128, 64, 64>), grid, dim3(256), 0, stream, p); break;   // 4 waves of 64 x 64
         case 9: hipLaunchKernelGGL((conv_ring_kernel<128, 128, 32, 64>), grid, dim3(512), 0, stream, p); break;   // 8 waves of 32 x 64
+        case 3: hipLaunchKernelGGL((conv_ring_kernel<96, 128, 96, 32>), dim3((p.M + 95) / 96, grid.y, grid.z), dim3(256), 0, stream, p); break;   // 96 x 128: 4 waves of 96 x 32
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

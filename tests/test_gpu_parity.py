@@ -74,7 +74,7 @@ def test_op_conv1d(hip, B, L, Cin, Cout, K, stride, tr, act):
 
 def test_conv_tile_shapes_agree(hip):
     """Every tile shape of conv_gemm_f32 (64x64 ... 160x128) and both engines — global -> VGPR -> LDS staging (conv_gemm.hip) and the
-    LDS-DMA ring with 4 / 8 waves per tile (conv_gemm_ring.hip: tiles 31 / 39; halo taps read a zero buffer, rows beyond M too) —
+    LDS-DMA ring with 4 / 8 waves per 128 x 128 tile and its 96 x 128 tile (conv_gemm_ring.hip: tiles 31 / 39 / 33; halo taps read a zero buffer, rows beyond M too) —
     walk K in the same order, so the outputs must be bit-identical; M = 225 and N = 200 are ragged against every tile height / width."""
     _lib, lib, ctx = hip
     rng = np.random.default_rng(77)
@@ -90,7 +90,7 @@ def test_conv_tile_shapes_agree(hip):
     ref = np.where(ref >= 0, ref, 0.2 * ref).astype(np.float32)
     xd, wd, bd = dev(x), dev(w), dev(b)
     outs = {}
-    for tile in (1, 2, 3, 4, 5, 6, 7, 31, 39, 0):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 31, 33, 39, 0):
         out = torch.full((B, L, Cout), float("nan"), dtype=torch.float32, device="cuda")
         _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, tile, 1,
                                           _lib.dptr(out), None, None))
@@ -117,14 +117,14 @@ def test_conv_banded_launch_matches_plain_tiles(hip):
     b[:Cout] = rng.standard_normal(Cout).astype(np.float32)
     xd, wd, bd = dev(x), dev(w), dev(b)
     outs = {}
-    for tile in (0, 1, 2, 31, 39):       # 31 / 39: the ring engine on a plain 128 x 128 grid
+    for tile in (0, 1, 2, 31, 33, 39):   # 31 / 39 / 33: the ring engine on a plain grid of 128 x 128 / 96 x 128 tiles
         out = torch.full((B, L, Cout), float("nan"), dtype=torch.float32, device="cuda")
         _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, tile, 1,
                                           _lib.dptr(out), None, None))
         torch.cuda.synchronize()
         outs[tile] = out.cpu().numpy()
     assert np.isfinite(outs[0]).all()
-    for tile in (1, 2, 31, 39):
+    for tile in (1, 2, 31, 33, 39):
         assert np.array_equal(outs[0], outs[tile]), f"tile {tile} differs from the banded launch"
     rows = rng.integers(0, L, 64)
     xp = np.pad(x, ((0, 0), (1, 1), (0, 0)))

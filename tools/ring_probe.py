@@ -22,7 +22,7 @@ lib = _lib.load()
 ctx = _lib.context(0)
 ROUNDS = int(os.environ.get("TS_ROUNDS", "3"))
 TILES = [int(t) for t in os.environ.get("TS_TILES", "0,1,31,39").split(",")]
-NAMES = {0: "prod", 1: "reg128", 4: "reg64x128", 31: "ring 4w", 39: "ring 8w"}
+NAMES = {0: "prod", 1: "reg128", 4: "reg64x128", 6: "reg160x128", 7: "reg96x128", 31: "ring 4w", 33: "ring 96x128", 39: "ring 8w"}
 # (B, L, Cin, Cout, K, tag)
 SHAPES = [
     (64, 300, 768, 2304, 1, "qkv"), (64, 300, 768, 768, 1, "out-proj"), (64, 300, 768, 3072, 1, "ffn1"), (64, 300, 3072, 768, 1, "ffn2"),
