@@ -43,10 +43,16 @@ int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int g
  * whose weights are ALREADY packed on the device as [round128(Cout)][K*Cin] (tap-major, k contiguous), launched
  * `iters` times between two HIP events recorded on `stream`; tile: 0 = production heuristic, 1 = 128x128,
  * 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 with 64-deep K chunks, 6 = 160x128, 7 = 96x128; 31 / 39 / 33 = the LDS-DMA ring engine's
- * 128x128 tile with 4 / 8 waves and its 96x128 tile (conv_gemm_ring.hip).  *ms_out = mean launch duration in milliseconds. */
+ * 128x128 tile with 4 / 8 waves and its 96x128 tile (conv_gemm_ring.hip), 35 / 36 = 39 / 33 with the tiles dealt to the XCDs in blocks that
+ * share operands.  *ms_out = mean launch duration in milliseconds. */
 int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
                        const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
                        void *stream);
+/* The same for a strided convolution without padding + GELU — the shape of the wav2vec2 feature convolutions
+ * (out[t] = sum_k W_k x[stride t + k], HF Wav2Vec2FeatureEncoder; K <= 4): out_dev is (B, (Lin - K) / stride + 1, Cout). */
+int ts_op_conv1d_strided_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
+                               const float *bias_dev, int Cout, int K, int stride, int tile, int iters, float *out_dev,
+                               float *ms_out, void *stream);
 
 /* Host-only helper (no GPU needed): the tile height (128 or 96 rows, 128 columns) conv_gemm_f32's LDS-DMA ring engine gives a single-problem
  * layer of M rows x N columns — by tile count: rounds of 512 resident workgroups, a last round at most half full costs half a round

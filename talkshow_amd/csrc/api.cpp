@@ -26,6 +26,7 @@ const Knobs &knobs() {
         auto num = [](const char *name, int dflt) { const char *e = std::getenv(name); return e && e[0] ? std::atoi(e) : dflt; };
         v.conv_bands = num("TS_CONV_BANDS", 1) != 0;
         v.conv_ring = num("TS_CONV_RING", 9);
+        v.conv_deal = num("TS_CONV_DEAL", 1) != 0;
         v.vq_lds = num("TS_VQ_LDS", 1) != 0;
         v.split_xcd = num("TS_SPLIT_XCD", 8);
         v.prof_log = num("TS_PROF_LOG", 0) != 0;
@@ -219,6 +220,48 @@ int ts_op_conv1d_timed(ts_ctx *ctx, const float *x, int B, int Lin, int Cin, con
     p.g[0].out = out;
     p.g[0].nseg = K;
     for (int k = 0; k < K; ++k) p.g[0].seg[k] = ConvSeg{K == 1 ? 0 : k - 1, 0, Cin};
+    hipEvent_t a, b;
+    TS_HIP(hipEventCreate(&a));
+    TS_HIP(hipEventCreate(&b));
+    TS_HIP(launch_conv_gemm(p, tile, s));   // warm-up
+    TS_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) TS_HIP(launch_conv_gemm(p, tile, s));
+    TS_HIP(hipEventRecord(b, s));
+    TS_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    TS_HIP(hipEventElapsedTime(&ms, a, b));
+    if (ms_out) *ms_out = ms / (iters > 0 ? iters : 1);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return 0;
+}
+
+// the same for a strided convolution without padding (the wav2vec2 feature convolutions: out[t] = sum_k W_k x[stride t + k]);
+// out: (B, (Lin - K) / stride + 1, Cout)
+int ts_op_conv1d_strided_timed(ts_ctx *ctx, const float *x, int B, int Lin, int Cin, const float *w_packed_dev,
+                               const float *bias_dev, int Cout, int K, int stride, int tile, int iters, float *out,
+                               float *ms_out, void *stream) {
+    if (!ctx || !x || !w_packed_dev || !out) return fail("ts_op_conv1d_strided_timed: null argument");
+    if (Cin % 32 || K < 1 || K > 4 || stride < 1 || Lin < K) return fail("ts_op_conv1d_strided_timed: unsupported geometry");
+    hipStream_t s = (hipStream_t)stream;
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.Lin = Lin;
+    p.Lout = (Lin - K) / stride + 1;
+    p.M = B * p.Lout;
+    p.stride = stride;
+    p.ldx = Cin;
+    p.ldo = Cout;
+    p.N = Cout;
+    p.Ktot = K * Cin;
+    p.act = 3;
+    p.ngroups = 1;
+    p.g[0].x = x;
+    p.g[0].w = w_packed_dev;
+    p.g[0].bias = bias_dev;
+    p.g[0].out = out;
+    p.g[0].nseg = K;
+    for (int k = 0; k < K; ++k) p.g[0].seg[k] = ConvSeg{k, 0, Cin};
     hipEvent_t a, b;
     TS_HIP(hipEventCreate(&a));
     TS_HIP(hipEventCreate(&b));

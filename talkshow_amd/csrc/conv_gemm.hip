@@ -353,11 +353,13 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
     auto grid = [&](int bm, int bn) { return dim3((p.M + bm - 1) / bm, (p.N + bn - 1) / bn, p.ngroups); };
     // zero buffer (ts::skinny_init, called by ts_ctx_create): 64 Ki floats; parked pointers walk at most Ktot floats of it
     if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000) return hipErrorInvalidValue;
-    if (tile == 31 || tile == 33 || tile == 39) return launch_conv_gemm_ring(p, tile - 30, stream);   // LDS-DMA ring engine (conv_gemm_ring.hip)
+    if (tile == 31 || tile == 33 || tile == 39 || tile == 35 || tile == 36) return launch_conv_gemm_ring(p, tile - 30, stream);   // LDS-DMA ring engine (conv_gemm_ring.hip)
     // single-problem layers that take 128 x 128 tiles (the face generator's GEMMs) run on the ring engine; the paired body + hand
     // layers keep the banded launch below (same-box A/B: profiles/r05_notes/ring_conv_stacks_ab.txt, ring_face_ab.txt)
-    if (tile == 0 && knobs().conv_ring > 0 && p.ngroups == 1 && p.zdiv == 0 && pick_tile(p) == 1 && conv_gemm_ring_takes(p))
-        return launch_conv_gemm_ring(p, knobs().conv_ring == 9 ? 0 : (knobs().conv_ring == 8 ? 9 : knobs().conv_ring), stream);   // 0: 128 x 128 on 8 waves or 96 x 128, by tile count
+    if (tile == 0 && knobs().conv_ring > 0 && p.ngroups == 1 && p.zdiv == 0 && pick_tile(p) == 1 && conv_gemm_ring_takes(p)) {
+        const int v = knobs().conv_ring;   // 9: 128 x 128 on 8 waves or 96 x 128, by tile count; tiles dealt to the XCDs unless TS_CONV_DEAL=0
+        return launch_conv_gemm_ring(p, v == 9 ? (knobs().conv_deal ? 10 : 0) : (v == 8 ? 9 : v), stream);
+    }
     if (tile == 0 && pick_tile(p) == 1) {
         const bool banded = knobs().conv_bands;   // TS_CONV_BANDS=0: plain grid (A/B, tests)
         ConvBands bd;

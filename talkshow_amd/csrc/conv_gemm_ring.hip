@@ -17,7 +17,11 @@
 //   * ring of NS = 2 stage slots; stage t + 1 is issued behind the barrier that opens stage t; the barrier that opens stage t + 1
 //     sits in the middle of stage t's last MFMA group: one barrier per stage, no staging registers, no ds_write, 94-150 VGPRs;
 //   * 8 waves per workgroup (32 x 64 outputs each: 4 x 2 waves), two workgroups per CU: four waves per SIMD, two even when a
-//     workgroup is alone on its CU in the tail of a launch.
+//     workgroup is alone on its CU in the tail of a launch;
+//   * tiles DEALT to the XCDs (1-D grid, ids round-robin over the 8 XCDs, XCD c takes the c-th contiguous eighth of a tile list
+//     ordered by column groups, columns fastest: split_tile_of, kernels.h): the 64 workgroups resident on an XCD share their
+//     operand tiles in ITS L2.  Nothing on cache-resident layers (M = 19 200: +0 ... 1.6 %), +7-8 % on the feature convolutions
+//     (M up to 1 023 936 rows: 124.7 -> 135.0 TFLOP/s), whose rows otherwise cross the fabric once per column tile.
 // What was measured on the way (tools/ring_probe.py, profiles/r05_notes/, tools/experiments/README.md): the main loop runs at the
 // matrix pipe's rate (3.45 us per stage against 3.41 us at 2.4 GHz; asymptotically 141 TFLOP/s), also for a workgroup alone on its
 // CU; what separates a K = 768 layer (115-128 TFLOP/s) from that is K-independent: ~13 us per launch, ~6 us per further round of
@@ -237,11 +241,18 @@ __device__ __forceinline__ void ring_tile(const ConvParams &p, const int zidx, c
     conv_tile_epilogue<TM, TN>(p, g, tp, acc, m0 + wm * WM, n0 + wn * WN, li, lh);   // conv_tile.h
 }
 
-// two workgroups per CU
-template <int BM, int BN, int WM, int WN>
+// two workgroups per CU.  XCD = false: grid (row tiles, column tiles, problems).  XCD = true: 1-D grid of 8 ceil(tiles / 8) per problem, tiles
+// dealt to the XCDs by split_tile_of (kernels.h): an XCD's 64 resident workgroups are blocks of up to 8 x 8 tiles that share their operand
+// tiles in its L2 — the same tiles, the same bits
+template <int BM, int BN, int WM, int WN, bool XCD>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) / 2) void conv_ring_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * (BM + BN) * 32];
-    ring_tile<BM, BN, WM, WN>(p, blockIdx.z, blockIdx.x * BM, blockIdx.y * BN, smem);
+    int tx = blockIdx.x, ty = blockIdx.y;
+    if constexpr (XCD) {
+        const int nt = (p.N + BN - 1) / BN;
+        if (!split_tile_of((int)blockIdx.x, (p.M + BM - 1) / BM, nt, nt < 8 ? nt : 8, tx, ty)) return;
+    }
+    ring_tile<BM, BN, WM, WN>(p, blockIdx.z, tx * BM, ty * BN, smem);
 }
 
 bool conv_gemm_ring_takes(const ConvParams &p) {
@@ -278,11 +289,15 @@ hipError_t launch_conv_gemm_ring(const ConvParams &p_in, int variant, hipStream_
     }
     if (!p.zero || !conv_gemm_ring_takes(p)) return hipErrorInvalidValue;
     if (variant == 0) variant = conv_gemm_ring_pick(p);
+    if (variant == 10) variant = conv_gemm_ring_pick(p) == 3 ? 6 : 5;   // the pick, tiles dealt to the XCDs
     const dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.ngroups);
+    auto dealt = [&](int bm) { return dim3(8 * (unsigned)(((long)((p.M + bm - 1) / bm) * grid.y + 7) / 8), 1, grid.z); };
     switch (variant) {
-        case 1: hipLaunchKernelGGL((conv_ring_kernel<128, 128, 64, 64>), grid, dim3(256), 0, stream, p); break;   // 4 waves of 64 x 64
-        case 9: hipLaunchKernelGGL((conv_ring_kernel<128, 128, 32, 64>), grid, dim3(512), 0, stream, p); break;   // 8 waves of 32 x 64
-        case 3: hipLaunchKernelGGL((conv_ring_kernel<96, 128, 96, 32>), dim3((p.M + 95) / 96, grid.y, grid.z), dim3(256), 0, stream, p); break;   // 96 x 128: 4 waves of 96 x 32
+        case 1: hipLaunchKernelGGL((conv_ring_kernel<128, 128, 64, 64, false>), grid, dim3(256), 0, stream, p); break;   // 4 waves of 64 x 64
+        case 9: hipLaunchKernelGGL((conv_ring_kernel<128, 128, 32, 64, false>), grid, dim3(512), 0, stream, p); break;   // 8 waves of 32 x 64
+        case 3: hipLaunchKernelGGL((conv_ring_kernel<96, 128, 96, 32, false>), dim3((p.M + 95) / 96, grid.y, grid.z), dim3(256), 0, stream, p); break;   // 96 x 128: 4 waves of 96 x 32
+        case 5: hipLaunchKernelGGL((conv_ring_kernel<128, 128, 32, 64, true>), dealt(128), dim3(512), 0, stream, p); break;   // 9 with the tiles dealt to the XCDs
+        case 6: hipLaunchKernelGGL((conv_ring_kernel<96, 128, 96, 32, true>), dealt(96), dim3(256), 0, stream, p); break;     // 3 likewise
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

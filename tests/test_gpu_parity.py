@@ -74,7 +74,8 @@ def test_op_conv1d(hip, B, L, Cin, Cout, K, stride, tr, act):
 
 def test_conv_tile_shapes_agree(hip):
     """Every tile shape of conv_gemm_f32 (64x64 ... 160x128) and both engines — global -> VGPR -> LDS staging (conv_gemm.hip) and the
-    LDS-DMA ring with 4 / 8 waves per 128 x 128 tile and its 96 x 128 tile (conv_gemm_ring.hip: tiles 31 / 39 / 33; halo taps read a zero buffer, rows beyond M too) —
+    LDS-DMA ring with 4 / 8 waves per 128 x 128 tile and its 96 x 128 tile (conv_gemm_ring.hip: tiles 31 / 39 / 33, and 35 / 36 = 39 / 33 with the tiles
+    dealt to the XCDs on a 1-D grid — what production launches; halo taps read a zero buffer, rows beyond M too) —
     walk K in the same order, so the outputs must be bit-identical; M = 225 and N = 200 are ragged against every tile height / width."""
     _lib, lib, ctx = hip
     rng = np.random.default_rng(77)
@@ -90,13 +91,43 @@ def test_conv_tile_shapes_agree(hip):
     ref = np.where(ref >= 0, ref, 0.2 * ref).astype(np.float32)
     xd, wd, bd = dev(x), dev(w), dev(b)
     outs = {}
-    for tile in (1, 2, 3, 4, 5, 6, 7, 31, 33, 39, 0):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 31, 33, 39, 35, 36, 0):
         out = torch.full((B, L, Cout), float("nan"), dtype=torch.float32, device="cuda")
         _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, tile, 1,
                                           _lib.dptr(out), None, None))
         torch.cuda.synchronize()
         outs[tile] = out.cpu().numpy()
     np.testing.assert_allclose(outs[2], ref, atol=2e-5, rtol=1e-5)
+    for tile, o in outs.items():
+        assert np.array_equal(o, outs[2]), f"tile {tile} differs from the 64x64 tile"
+
+
+def test_strided_conv_tiles_agree(hip):
+    """The wav2vec2 feature convolutions' shape (k = 3, stride 2, no padding, GELU; HF Wav2Vec2FeatureEncoder under
+    nets/spg/wav2vec.py) through every engine / tile order that can carry it: bit-identical, and equal to a float64 restatement."""
+    import math
+    _lib, lib, ctx = hip
+    rng = np.random.default_rng(79)
+    B, L, Cin, Cout, K, stride = 3, 1201, 64, 200, 3, 2
+    Lout = (L - K) // stride + 1
+    x = rng.standard_normal((B, L, Cin)).astype(np.float32)
+    npad = (Cout + 127) // 128 * 128
+    w = np.zeros((npad, K * Cin), np.float32)
+    w[:Cout] = rng.standard_normal((Cout, K * Cin)).astype(np.float32) / np.sqrt(K * Cin)
+    b = np.zeros(npad, np.float32)
+    b[:Cout] = rng.standard_normal(Cout).astype(np.float32)
+    pre = sum(x[:, k:k + stride * (Lout - 1) + 1:stride, :].astype(np.float64) @ w[:Cout, k * Cin:(k + 1) * Cin].T.astype(np.float64)
+              for k in range(K)) + b[:Cout]
+    ref = 0.5 * pre * (1.0 + np.vectorize(math.erf)(pre / math.sqrt(2.0)))
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    outs = {}
+    for tile in (2, 1, 0, 39, 35, 33, 36):
+        out = torch.full((B, Lout, Cout), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(lib.ts_op_conv1d_strided_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, stride, tile, 1,
+                                                  _lib.dptr(out), None, None))
+        torch.cuda.synchronize()
+        outs[tile] = out.cpu().numpy()
+    assert_close_measured("strided_conv_gelu", outs[2], ref, 2e-5)
     for tile, o in outs.items():
         assert np.array_equal(o, outs[2]), f"tile {tile} differs from the 64x64 tile"
 
@@ -117,14 +148,14 @@ def test_conv_banded_launch_matches_plain_tiles(hip):
     b[:Cout] = rng.standard_normal(Cout).astype(np.float32)
     xd, wd, bd = dev(x), dev(w), dev(b)
     outs = {}
-    for tile in (0, 1, 2, 31, 33, 39):   # 31 / 39 / 33: the ring engine on a plain grid of 128 x 128 / 96 x 128 tiles
+    for tile in (0, 1, 2, 31, 33, 39, 35, 36):   # 31 / 39 / 33: the ring engine on a plain grid of 128 x 128 / 96 x 128 tiles; 35 / 36: tiles dealt to the XCDs (604 / 804 tiles: padding workgroups idle)
         out = torch.full((B, L, Cout), float("nan"), dtype=torch.float32, device="cuda")
         _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, tile, 1,
                                           _lib.dptr(out), None, None))
         torch.cuda.synchronize()
         outs[tile] = out.cpu().numpy()
     assert np.isfinite(outs[0]).all()
-    for tile in (1, 2, 31, 33, 39):
+    for tile in (1, 2, 31, 33, 39, 35, 36):
         assert np.array_equal(outs[0], outs[tile]), f"tile {tile} differs from the banded launch"
     rows = rng.integers(0, L, 64)
     xp = np.pad(x, ((0, 0), (1, 1), (0, 0)))
@@ -1056,10 +1087,12 @@ def test_wav_in_code_stability(hip, tmp_path):
                                  {"TS_SKINNY_SHAPE": "22"}, {"TS_SKINNY_SHAPE": "42"},
                                  {"TS_SKINNY_TILED": "0", "TS_WITH_CLIPS": "1"}, {"TS_PIX_DEFER_P": "0", "TS_WITH_CLIPS": "1"},
                                  {"TS_PIX_DEFER_P": "1", "TS_WITH_CLIPS": "1"}, {"TS_SKINNY_WIDE_MIN": "0", "TS_WITH_CLIPS": "1"},
-                                 {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}, {"TS_VQ_LDS": "0", "TS_CONV_RING": "0", "TS_WITH_VQ": "1"}],
+                                 {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}, {"TS_VQ_LDS": "0", "TS_CONV_RING": "0", "TS_WITH_VQ": "1"},
+                                 {"TS_CONV_DEAL": "0", "TS_WITH_VQ": "1"}],
                          ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
                               "row_major_operands", "projections_in_column0", "projections_in_column1",
-                              "split_k_kernels_only", "wide_kernel_everywhere", "per_thread_vq_search_and_register_staged_conv"])
+                              "split_k_kernels_only", "wide_kernel_everywhere", "per_thread_vq_search_and_register_staged_conv",
+                              "ring_conv_on_a_plain_grid"])
 def test_alternate_kernel_paths(hip, env):
     """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
     launches, the 32-column kernel), row-major instead of tiled operands, two placements of the next-row projections, and

@@ -246,7 +246,7 @@ def test_conv_band_plan_covers_every_row_once():
 
 
 def test_split_gemm_tile_order_covers_every_tile_once():
-    """`conv_gemm_split` (the opt-in bf16x3 face plan) runs on a 1-D grid whose workgroups pick their tile through `split_tile_of`
+    """`conv_gemm_split` (the opt-in bf16x3 face plan) and `conv_gemm_f32`'s ring engine run on a 1-D grid whose workgroups pick their tile through `split_tile_of`
     (`csrc/kernels.h`, the same function on the device and here): ids go round-robin over the 8 XCDs, XCD x takes the x-th eighth of a
     tile list ordered by column groups.  Host logic, no GPU: every tile exactly once, padding workgroups get none, and the 64 workgroups
     an XCD holds at a time (64 consecutive list positions) touch few distinct row and column tiles — that is the point of the order."""
@@ -254,7 +254,8 @@ def test_split_gemm_tile_order_covers_every_tile_once():
     from talkshow_amd import _lib
     lib = _lib.load()
     out = (C.c_int * 2)()
-    for MT, NT, gw in ((150, 6, 8), (150, 18, 8), (150, 24, 8), (8000, 4, 8), (2, 1, 8), (37, 11, 4), (5, 5, 8), (150, 24, 6)):
+    for MT, NT, gw in ((150, 6, 8), (150, 18, 8), (150, 24, 8), (8000, 4, 8), (2, 1, 8), (37, 11, 4), (5, 5, 8), (150, 24, 6),
+                       (8000, 4, 4), (200, 6, 6), (151, 4, 4), (2000, 4, 4)):   # conv_gemm_f32's ring engine: width min(NT, 8) (conv_gemm_ring.hip)
         total, per = MT * NT, -(-MT * NT // 8)
         seen, by_xcd = set(), {x: [] for x in range(8)}
         for bid in range(per * 8):
