@@ -54,6 +54,13 @@ int ts_op_conv1d_strided_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, 
                                const float *bias_dev, int Cout, int K, int stride, int tile, int iters, float *out_dev,
                                float *ms_out, void *stream);
 
+/* Tuning / test entry for conv_taps48.hip (the wav2vec2 positional convolution, HF Wav2Vec2PositionalConvEmbedding + the encoder's residual
+ * add): grouped convolution with G groups of 48 channels in and out, `ntap` taps -ntap / 2 .. ntap - ntap / 2 - 1 with zero padding, out = GELU(conv +
+ * bias) + res.  x_dev / res_dev (optional) / out_dev: (B, T, G * 48); w_dev: [G][48][ntap * 48] (tap-major, a tap's 48 input channels contiguous);
+ * bias_dev: [G * 48].  `iters` launches between two HIP events; *ms_out = mean launch duration in milliseconds. */
+int ts_op_conv_taps48_timed(ts_ctx *ctx, const float *x_dev, int B, int T, int G, int ntap, const float *w_dev, const float *bias_dev,
+                            const float *res_dev, int iters, float *out_dev, float *ms_out, void *stream);
+
 /* Host-only helper (no GPU needed): the tile height (128 or 96 rows, 128 columns) conv_gemm_f32's LDS-DMA ring engine gives a single-problem
  * layer of M rows x N columns — by tile count: rounds of 512 resident workgroups, a last round at most half full costs half a round
  * (csrc/conv_gemm_ring.hip::conv_gemm_ring_pick).  -1 on a bad argument.  No reference counterpart. */

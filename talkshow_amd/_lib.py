@@ -74,6 +74,7 @@ SIGNATURES = {
     "ts_body_vq_infer": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ts_op_conv1d": (_i, [_vp, _vp, _i, _i, _i, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ts_op_conv1d_timed": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
+    "ts_op_conv_taps48_timed": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, C.POINTER(C.c_float), _vp]),
     "ts_op_conv1d_strided_timed": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
     "ts_debug_pixelcnn_graphs": (_i, [_vp, _vp]),
     "ts_debug_conv_ring_pick": (_i, [_i, _i, _i]),

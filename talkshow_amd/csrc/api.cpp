@@ -27,6 +27,7 @@ const Knobs &knobs() {
         v.conv_bands = num("TS_CONV_BANDS", 1) != 0;
         v.conv_ring = num("TS_CONV_RING", 9);
         v.conv_deal = num("TS_CONV_DEAL", 1) != 0;
+        v.conv_taps48 = num("TS_CONV_TAPS48", 1) != 0;
         v.vq_lds = num("TS_VQ_LDS", 1) != 0;
         v.split_xcd = num("TS_SPLIT_XCD", 8);
         v.prof_log = num("TS_PROF_LOG", 0) != 0;
@@ -268,6 +269,50 @@ int ts_op_conv1d_strided_timed(ts_ctx *ctx, const float *x, int B, int Lin, int 
     TS_HIP(launch_conv_gemm(p, tile, s));   // warm-up
     TS_HIP(hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) TS_HIP(launch_conv_gemm(p, tile, s));
+    TS_HIP(hipEventRecord(b, s));
+    TS_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    TS_HIP(hipEventElapsedTime(&ms, a, b));
+    if (ms_out) *ms_out = ms / (iters > 0 ? iters : 1);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return 0;
+}
+
+// grouped many-tap convolution, 48 channels per group in and out (conv_taps48.hip: the wav2vec2 positional conv): x, res, out
+// (B, T, G * 48); w [G][48][ntap * 48] (tap-major, channels contiguous); bias [G * 48]; out = GELU(conv + bias) + res, taps
+// -ntap / 2 .. ntap - ntap / 2 - 1, zero padding
+int ts_op_conv_taps48_timed(ts_ctx *ctx, const float *x, int B, int T, int G, int ntap, const float *w, const float *bias,
+                            const float *res, int iters, float *out, float *ms_out, void *stream) {
+    if (!ctx || !x || !w || !out) return fail("ts_op_conv_taps48_timed: null argument");
+    if (B < 1 || T < 1 || G < 1 || ntap < 1) return fail("ts_op_conv_taps48_timed: unsupported geometry");
+    hipStream_t s = (hipStream_t)stream;
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.M = B * T;
+    p.Lout = p.Lin = T;
+    p.stride = 1;
+    p.ldx = p.ldo = p.ldr = G * 48;
+    p.N = 48;
+    p.Ktot = ntap * 48;
+    p.act = 3;
+    p.res_after_act = 1;
+    p.ngroups = p.zdiv = G;
+    p.x_zs1 = p.o_zs1 = p.r_zs1 = p.b_zs1 = 48;
+    p.w_zs1 = 48L * p.Ktot;
+    p.g[0].x = x;
+    p.g[0].w = w;
+    p.g[0].bias = bias;
+    p.g[0].res = res;
+    p.g[0].out = out;
+    p.g[0].nseg = 1;
+    p.g[0].seg[0] = ConvSeg{-(ntap / 2), 0, 48, ntap};
+    hipEvent_t a, b;
+    TS_HIP(hipEventCreate(&a));
+    TS_HIP(hipEventCreate(&b));
+    TS_HIP(launch_conv_gemm(p, 48, s));   // warm-up
+    TS_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) TS_HIP(launch_conv_gemm(p, 48, s));
     TS_HIP(hipEventRecord(b, s));
     TS_HIP(hipEventSynchronize(b));
     float ms = 0.f;

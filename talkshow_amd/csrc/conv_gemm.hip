@@ -354,6 +354,7 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
     // zero buffer (ts::skinny_init, called by ts_ctx_create): 64 Ki floats; parked pointers walk at most Ktot floats of it
     if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000) return hipErrorInvalidValue;
     if (tile == 31 || tile == 33 || tile == 39 || tile == 35 || tile == 36) return launch_conv_gemm_ring(p, tile - 30, stream);   // LDS-DMA ring engine (conv_gemm_ring.hip)
+    if (tile == 48 || (tile == 0 && knobs().conv_taps48 && conv_taps48_takes(p))) return launch_conv_taps48(p, stream);   // grouped 48-channel taps, unpadded (conv_taps48.hip)
     // single-problem layers that take 128 x 128 tiles (the face generator's GEMMs) run on the ring engine; the paired body + hand
     // layers keep the banded launch below (same-box A/B: profiles/r05_notes/ring_conv_stacks_ab.txt, ring_face_ab.txt)
     if (tile == 0 && knobs().conv_ring > 0 && p.ngroups == 1 && p.zdiv == 0 && pick_tile(p) == 1 && conv_gemm_ring_takes(p)) {

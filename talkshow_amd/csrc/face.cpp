@@ -89,6 +89,7 @@ struct ts_face {
     LNp fp_ln;
     ConvLayer fp_proj;
     DevBuf pos_w, pos_b, pos_wp;
+    DevBuf pos_wd;   // the same weights unpadded, [group][48][taps * 48] (conv_taps48.hip); empty unless the group width is 48
     int pos_npad = 128, pos_ktot = 0;
     LNp enc_ln;
     std::vector<std::unique_ptr<EncLayer>> layers;
@@ -177,6 +178,15 @@ int ts_face_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int n_layers, int n
             }
         TS_TRY(up(f->pos_w, wp.data(), wp.size()));
         TS_TRY(up(f->pos_b, bp.data(), bp.size()));
+        if (cg == 48) {
+            std::vector<float> wd((size_t)G * cg * K * cg);
+            for (int gi = 0; gi < G; ++gi)
+                for (int o = 0; o < cg; ++o)
+                    for (int k = 0; k < K; ++k)
+                        for (int c = 0; c < cg; ++c)
+                            wd[(((size_t)gi * cg + o) * K + k) * cg + c] = wp[((size_t)gi * npad + o) * f->pos_ktot + (size_t)k * cpad + c];
+            TS_TRY(up(f->pos_wd, wd.data(), wd.size()));
+        }
     }
     TS_TRY(load_ln(sd, p + "encoder.layer_norm", HID, &f->enc_ln));
     for (int l = 0; l < n_layers; ++l) {
@@ -374,6 +384,12 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
         G.out = w.TMP.f();
         G.nseg = 1;
         G.seg[0] = ConvSeg{-(f->POSK / 2), 0, 64, f->POSK};
+        if (!f->split_planes && f->pos_wd.p && ts::knobs().conv_taps48) {   // unpadded: 48-channel taps, 48 weight rows per group (conv_taps48.hip)
+            p.Ktot = f->POSK * cg;
+            p.w_zs1 = (long)cg * p.Ktot;
+            G.w = f->pos_wd.f();
+            G.seg[0].len = cg;
+        }
         TS_TRY(run_conv(ctx, p, f->split_planes ? 20 + f->split_planes : 0, s));
     }
     TS_TRY(ln(w.TMP.f(), HID, f->enc_ln, nullptr, 0, w.H.f()));

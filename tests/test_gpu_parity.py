@@ -132,6 +132,39 @@ def test_strided_conv_tiles_agree(hip):
         assert np.array_equal(o, outs[2]), f"tile {tile} differs from the 64x64 tile"
 
 
+@pytest.mark.parametrize("B,T,G,ntap,with_res", [(2, 75, 2, 16, True), (3, 131, 16, 128, True), (1, 5, 1, 128, False), (2, 300, 3, 7, True)])
+def test_grouped_taps48_conv(hip, B, T, G, ntap, with_res):
+    """conv_taps48.hip — the wav2vec2 positional convolution (HF Wav2Vec2PositionalConvEmbedding: Conv1d(768, 768, 128, padding 64, groups 16),
+    last frame dropped, GELU; + the encoder's residual) unpadded on the 16 x 16 MFMA — against a float64 restatement: clips shorter than the
+    kernel (every tap partly in the zero padding), row counts ragged against the 128-row tile, odd tap counts."""
+    import math
+    _lib, lib, ctx = hip
+    rng = np.random.default_rng(80 + T)
+    C = G * 48
+    x = rng.standard_normal((B, T, C)).astype(np.float32)
+    w = (rng.standard_normal((G, 48, ntap, 48)) / np.sqrt(ntap * 48)).astype(np.float32)     # [group][out][tap][in]
+    bias = rng.standard_normal(C).astype(np.float32)
+    res = rng.standard_normal((B, T, C)).astype(np.float32) if with_res else None
+    d0 = -(ntap // 2)
+    xp = np.zeros((B, T + 2 * ntap, C), np.float64)
+    xp[:, ntap:ntap + T] = x
+    pre = np.zeros((B, T, C), np.float64)
+    for g in range(G):
+        for k in range(ntap):
+            pre[:, :, g * 48:(g + 1) * 48] += xp[:, ntap + d0 + k:ntap + d0 + k + T, g * 48:(g + 1) * 48] @ w[g, :, k, :].T.astype(np.float64)
+    pre += bias
+    ref = 0.5 * pre * (1.0 + np.vectorize(math.erf)(pre / math.sqrt(2.0)))
+    if with_res:
+        ref = ref + res
+    out = torch.full((B, T, C), float("nan"), dtype=torch.float32, device="cuda")
+    xd, wd, bd = dev(x), dev(w.reshape(G, 48, ntap * 48)), dev(bias)
+    rd = dev(res) if with_res else None
+    _lib.check(lib.ts_op_conv_taps48_timed(ctx, _lib.dptr(xd), B, T, G, ntap, _lib.dptr(wd), _lib.dptr(bd), _lib.dptr(rd) if with_res else None, 1,
+                                           _lib.dptr(out), None, None))
+    torch.cuda.synchronize()
+    assert_close_measured(f"conv_taps48.B{B}T{T}G{G}K{ntap}", out.cpu().numpy(), ref, 2e-5)
+
+
 def test_conv_banded_launch_matches_plain_tiles(hip):
     """Layers of more than one round of 512 workgroups are launched in two bands (128 x 128 tiles for the whole rounds, 64 x 128
     for the rows that are left: conv_gemm.hip `plan_bands`).  Every tile shape walks K in the same order, so the banded launch
@@ -1088,11 +1121,11 @@ def test_wav_in_code_stability(hip, tmp_path):
                                  {"TS_SKINNY_TILED": "0", "TS_WITH_CLIPS": "1"}, {"TS_PIX_DEFER_P": "0", "TS_WITH_CLIPS": "1"},
                                  {"TS_PIX_DEFER_P": "1", "TS_WITH_CLIPS": "1"}, {"TS_SKINNY_WIDE_MIN": "0", "TS_WITH_CLIPS": "1"},
                                  {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}, {"TS_VQ_LDS": "0", "TS_CONV_RING": "0", "TS_WITH_VQ": "1"},
-                                 {"TS_CONV_DEAL": "0", "TS_WITH_VQ": "1"}],
+                                 {"TS_CONV_DEAL": "0", "TS_CONV_TAPS48": "0", "TS_WITH_VQ": "1"}],
                          ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
                               "row_major_operands", "projections_in_column0", "projections_in_column1",
                               "split_k_kernels_only", "wide_kernel_everywhere", "per_thread_vq_search_and_register_staged_conv",
-                              "ring_conv_on_a_plain_grid"])
+                              "ring_conv_on_a_plain_grid_and_padded_positional_conv"])
 def test_alternate_kernel_paths(hip, env):
     """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
     launches, the 32-column kernel), row-major instead of tiled operands, two placements of the next-row projections, and
