@@ -44,7 +44,7 @@ int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int g
  * `iters` times between two HIP events recorded on `stream`; tile: 0 = production heuristic, 1 = 128x128,
  * 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 with 64-deep K chunks, 6 = 160x128, 7 = 96x128; 31 / 39 / 33 = the LDS-DMA ring engine's
  * 128x128 tile with 4 / 8 waves and its 96x128 tile (conv_gemm_ring.hip), 35 / 36 = 39 / 33 with the tiles dealt to the XCDs in blocks that
- * share operands.  *ms_out = mean launch duration in milliseconds. */
+ * share operands, 37 = bands (128 x 128 + 64 x 128 tiles) + dealt tiles.  *ms_out = mean launch duration in milliseconds. */
 int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
                        const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
                        void *stream);
@@ -61,9 +61,10 @@ int ts_op_conv1d_strided_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, 
 int ts_op_conv_taps48_timed(ts_ctx *ctx, const float *x_dev, int B, int T, int G, int ntap, const float *w_dev, const float *bias_dev,
                             const float *res_dev, int iters, float *out_dev, float *ms_out, void *stream);
 
-/* Host-only helper (no GPU needed): the tile height (128 or 96 rows, 128 columns) conv_gemm_f32's LDS-DMA ring engine gives a single-problem
- * layer of M rows x N columns — by tile count: rounds of 512 resident workgroups, a last round at most half full costs half a round
- * (csrc/conv_gemm_ring.hip::conv_gemm_ring_pick).  -1 on a bad argument.  No reference counterpart. */
+/* Host-only helper (no GPU needed): the tile plan conv_gemm_f32's LDS-DMA ring engine gives a layer of `groups` problems of M rows x N columns —
+ * 128 (128 x 128 tiles), 96 (96 x 128 tiles) or 64 (bands: 128 x 128 tiles for the whole rounds of 512 resident workgroups, 64 x 128 tiles for
+ * the rows that are left) — by tile count: a last round at most half full costs half a round (csrc/conv_gemm_ring.hip::conv_gemm_ring_pick).
+ * -1 on a bad argument.  No reference counterpart. */
 int ts_debug_conv_ring_pick(int M, int N, int groups);
 
 /* Test aid: out[i] = the chain kernels' gate activation tanh(v[i]) * sigmoid(p[i]) as they compute it (v_exp_f32 / v_rcp_f32 form,

@@ -27,6 +27,7 @@ const Knobs &knobs() {
         v.conv_bands = num("TS_CONV_BANDS", 1) != 0;
         v.conv_ring = num("TS_CONV_RING", 9);
         v.conv_deal = num("TS_CONV_DEAL", 1) != 0;
+        v.conv_ring_paired = num("TS_CONV_RING_PAIRED", 1) != 0;
         v.conv_taps48 = num("TS_CONV_TAPS48", 1) != 0;
         v.vq_lds = num("TS_VQ_LDS", 1) != 0;
         v.split_xcd = num("TS_SPLIT_XCD", 8);
@@ -330,7 +331,10 @@ int ts_debug_conv_ring_pick(int M, int N, int groups) {
     p.M = M;
     p.N = N;
     p.ngroups = groups;
-    return ts::conv_gemm_ring_pick(p) == 3 ? 96 : 128;
+    ts::ConvBands bd{};
+    const bool have = ts::conv_gemm_plan_bands(p, bd);
+    const int pick = ts::conv_gemm_ring_pick(p, have ? &bd : nullptr);
+    return pick == 3 ? 96 : (pick == 7 ? 64 : 128);
 }
 
 int ts_debug_gate_act(const float *v_dev, const float *p_dev, float *out_dev, long n, void *stream) {

@@ -325,7 +325,7 @@ static int pick_tile(const ConvParams &p) {
 
 // Bands for a layer that the cost model gives to 128 x 128 tiles: big tiles for as many whole rounds of 512 resident workgroups
 // as fit, 64 x 128 tiles for the rows that are left (measured against 64 x 64 and 128 x 64: tools/conv_mix_ab.sh).
-static bool plan_bands(const ConvParams &p, ConvBands &bd) {
+bool conv_gemm_plan_bands(const ConvParams &p, ConvBands &bd) {
     const int slots = 512;
     const int MT = (p.M + 127) / 128, NT = ((p.N + 127) / 128) * p.ngroups;
     const long total = (long)MT * NT;
@@ -341,7 +341,7 @@ static bool plan_bands(const ConvParams &p, ConvBands &bd) {
 }
 
 // host-only view of the launch plan (tests): would `launch_conv_gemm(p, 0, ...)` band this layer, and how
-bool conv_gemm_band_plan(const ConvParams &p, ConvBands &bd) { return pick_tile(p) == 1 && plan_bands(p, bd); }
+bool conv_gemm_band_plan(const ConvParams &p, ConvBands &bd) { return pick_tile(p) == 1 && conv_gemm_plan_bands(p, bd); }
 
 hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream) {
     ConvParams p = p_in;
@@ -354,17 +354,28 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
     // zero buffer (ts::skinny_init, called by ts_ctx_create): 64 Ki floats; parked pointers walk at most Ktot floats of it
     if (!p.zero || p.g[0].nseg > 4 || p.Ktot > 60000) return hipErrorInvalidValue;
     if (tile == 31 || tile == 33 || tile == 39 || tile == 35 || tile == 36) return launch_conv_gemm_ring(p, tile - 30, stream);   // LDS-DMA ring engine (conv_gemm_ring.hip)
+    if (tile == 37) {   // ring engine, banded + dealt (falls back to the dealt plain grid when the layer has no band plan)
+        ConvBands bd;
+        if (!conv_gemm_plan_bands(p, bd)) return launch_conv_gemm_ring(p, 5, stream);
+        return launch_conv_gemm_ring_banded(p, bd, stream);
+    }
     if (tile == 48 || (tile == 0 && knobs().conv_taps48 && conv_taps48_takes(p))) return launch_conv_taps48(p, stream);   // grouped 48-channel taps, unpadded (conv_taps48.hip)
-    // single-problem layers that take 128 x 128 tiles (the face generator's GEMMs) run on the ring engine; the paired body + hand
-    // layers keep the banded launch below (same-box A/B: profiles/r05_notes/ring_conv_stacks_ab.txt, ring_face_ab.txt)
-    if (tile == 0 && knobs().conv_ring > 0 && p.ngroups == 1 && p.zdiv == 0 && pick_tile(p) == 1 && conv_gemm_ring_takes(p)) {
-        const int v = knobs().conv_ring;   // 9: 128 x 128 on 8 waves or 96 x 128, by tile count; tiles dealt to the XCDs unless TS_CONV_DEAL=0
-        return launch_conv_gemm_ring(p, v == 9 ? (knobs().conv_deal ? 10 : 0) : (v == 8 ? 9 : v), stream);
+    // layers that take 128 x 128 tiles run on the ring engine (same-box A/B: profiles/r05_notes/): the face generator's GEMMs, and the paired
+    // body + hand layers unless TS_CONV_RING_PAIRED=0 (then: the banded launch below)
+    if (tile == 0 && knobs().conv_ring > 0 && (p.ngroups == 1 || knobs().conv_ring_paired) && p.zdiv == 0 && pick_tile(p) == 1 && conv_gemm_ring_takes(p)) {
+        const int v = knobs().conv_ring;   // 9: the tile plan by tile count (conv_gemm_ring_pick); tiles dealt to the XCDs unless TS_CONV_DEAL=0
+        if (v == 9 && knobs().conv_deal) {
+            ConvBands bd;
+            const bool have = knobs().conv_bands && conv_gemm_plan_bands(p, bd);
+            const int pick = conv_gemm_ring_pick(p, have ? &bd : nullptr);
+            return pick == 7 ? launch_conv_gemm_ring_banded(p, bd, stream) : launch_conv_gemm_ring(p, pick == 3 ? 6 : 5, stream);
+        }
+        return launch_conv_gemm_ring(p, v == 9 ? 0 : (v == 8 ? 9 : v), stream);
     }
     if (tile == 0 && pick_tile(p) == 1) {
         const bool banded = knobs().conv_bands;   // TS_CONV_BANDS=0: plain grid (A/B, tests)
         ConvBands bd;
-        if (banded && plan_bands(p, bd)) {
+        if (banded && conv_gemm_plan_bands(p, bd)) {
             hipLaunchKernelGGL((conv_gemm_banded_kernel<64, 128, 32, 64>), dim3(bd.total), block, 0, stream, p, bd);
             return hipGetLastError();
         }

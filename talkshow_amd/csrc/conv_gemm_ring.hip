@@ -255,6 +255,40 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM / WM) * (BN / WN) /
     ring_tile<BM, BN, WM, WN>(p, blockIdx.z, tx * BM, ty * BN, smem);
 }
 
+// Banded + dealt: rows [0, mt_big * 128) in 128 x 128 tiles for the whole rounds of 512 resident workgroups, the rows after them in
+// 64 x 128 tiles (conv_gemm.hip's plan_bands: the last, partly filled round of a layer is made of short tiles); per problem each band's
+// tiles are dealt to the XCDs (split_tile_of), every region padded to a multiple of 8 ids so that id mod 8 stays the XCD.
+// ids: [problem][big band, big8 ids] ..., then [problem][small band, small8 ids] ...
+__global__ __launch_bounds__(512, 4) void conv_ring_banded_kernel(const ConvParams p, const ConvBands bd, const int big8, const int small8) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * (128 + 128) * 32];
+    const int nt = (p.N + 127) / 128, gw = nt < 8 ? nt : 8;
+    int id = blockIdx.x, tx, ty;
+    const int nbig = big8 * p.ngroups;
+    if (id < nbig) {
+        const int z = id / big8;
+        if (!split_tile_of(id - z * big8, bd.mt_big, nt, gw, tx, ty)) return;
+        ring_tile<128, 128, 32, 64>(p, z, tx * 128, ty * 128, smem);
+    } else {
+        id -= nbig;
+        const int z = id / small8;
+        if (!split_tile_of(id - z * small8, bd.mt_small, nt, gw, tx, ty)) return;
+        ring_tile<64, 128, 32, 32>(p, z, bd.mt_big * 128 + tx * 64, ty * 128, smem);
+    }
+}
+
+hipError_t launch_conv_gemm_ring_banded(const ConvParams &p_in, const ConvBands &bd, hipStream_t stream) {
+    ConvParams p = p_in;
+    if (!p.zero) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) p.zero = skinny_zero_buffer(dev);
+    }
+    if (!p.zero || !conv_gemm_ring_takes(p) || p.zdiv > 0 || bd.mt_big < 1 || bd.mt_small < 1) return hipErrorInvalidValue;
+    const int nt = (p.N + 127) / 128;
+    const int big8 = 8 * ((bd.mt_big * nt + 7) / 8), small8 = 8 * ((bd.mt_small * nt + 7) / 8);
+    hipLaunchKernelGGL(conv_ring_banded_kernel, dim3((unsigned)((big8 + small8) * p.ngroups)), dim3(512), 0, stream, p, bd, big8, small8);
+    return hipGetLastError();
+}
+
 bool conv_gemm_ring_takes(const ConvParams &p) {
     if (p.g[0].nseg > 4 || p.Ktot > 60000 || p.Ktot < 32) return false;
     for (int z = 0; z < (p.zdiv > 0 ? 1 : p.ngroups); ++z)
@@ -263,22 +297,35 @@ bool conv_gemm_ring_takes(const ConvParams &p) {
     return true;
 }
 
-// Which tile for a single-problem layer?  A launch is rounds of 512 resident workgroups (two per CU); a workgroup alone on its CU
-// runs at the full pipe rate (tools/ring_probe.py: 256 tiles on 256 CUs take what 512 take), so a last round that is at most half
-// full costs half a round, a fuller one a whole round.  128 x 128 tiles on 8 waves are the fastest per tile; 96 x 128 tiles (4 waves
-// of 96 x 32, ~5 % slower per flop) change the tile COUNT: the N = 768 layers of the wav2vec2 blocks (900 tiles of 128 rows = 1.76
-// rounds -> 2; 1 200 of 96 rows = 2.34 rounds -> 2.5 x 0.75 = 1.875) take them — out-proj 207 -> 200 us, FFN2 750 -> 718 us inside a
-// face batch —, FFN1 (7.03 -> 7.5; 9.375 -> 9.5 x 0.75 = 7.125: a tie once the 5 % are counted) and QKV (5.27 -> 5.5 against 7.03 ->
-// 7.5 x 0.75 = 5.625) do not.  Measured: profiles/r05_notes/ring_tall_tiles.txt, face_layers_ab.txt.
-int conv_gemm_ring_pick(const ConvParams &p) {
+// Which tile plan for a layer?  A launch is rounds of 512 resident workgroups (two per CU); a workgroup alone on its CU runs at the full
+// pipe rate (tools/ring_probe.py: 256 tiles on 256 CUs take what 512 take), so a last round that is at most half full costs half a
+// round, a fuller one a whole round.  Three plans, cost = rounds x tile height / efficiency:
+//   9: 128 x 128 tiles on 8 waves, the fastest per tile;
+//   3: 96 x 128 tiles (4 waves of 96 x 32, ~5 % slower per flop) change the tile COUNT: the N = 768 layers of the wav2vec2 blocks (900 tiles
+//      of 128 rows = 1.76 rounds -> 2; 1 200 of 96 rows = 2.34 -> 2.5 x 0.75 = 1.875): out-proj 207 -> 200 us, FFN2 750 -> 718 us in a face batch;
+//   7: bands (conv_gemm.hip's plan, `bd`): 128 x 128 tiles for the whole rounds, 64 x 128 tiles (~7 % slower per flop) for the rows that
+//      are left: FFN1 (3 600 tiles = 7.03 rounds -> 6.98 + half a round of short tiles: 715 -> 693 us) and the paired body + hand layers
+//      (2 400 tiles = 4.69 rounds -> 4 + 1.5 short ones: conv stacks of a 256-clip pass 25.7 -> 25.2 ms); ties go to the plain plans.
+// Measured: profiles/r05_notes/ring_tall_tiles.txt, face_layers_ab.txt, ring_banded_probe.txt.
+int conv_gemm_ring_pick(const ConvParams &p, const ConvBands *bd) {
     const long nt = (long)((p.N + 127) / 128) * p.ngroups;
-    auto cost = [&](int bm, double eff) {
-        const long tiles = (long)((p.M + bm - 1) / bm) * nt;
+    auto rounds = [](long tiles) {
         const long full = tiles / 512, rest = tiles - full * 512;
-        const double rounds = (double)full + (rest == 0 ? 0.0 : (rest <= 256 ? 0.5 : 1.0));
-        return rounds * bm / eff;
+        return (double)full + (rest == 0 ? 0.0 : (rest <= 256 ? 0.5 : 1.0));
     };
-    return cost(96, 0.95) < cost(128, 1.0) ? 3 : 9;   // a 96 x 128 tile runs ~5 % below the 8-wave 128 x 128 tile per flop (layers without a tail: 122.7 vs 130.8, 114 vs 123 TFLOP/s)
+    const double c128 = rounds((long)((p.M + 127) / 128) * nt) * 128.0;
+    const double c96 = rounds((long)((p.M + 95) / 96) * nt) * 96.0 / 0.95;   // layers without a tail: 122.7 vs 130.8, 114 vs 123 TFLOP/s
+    double best = c128;
+    int pick = 9;
+    if (c96 < best) {
+        best = c96;
+        pick = 3;
+    }
+    if (bd) {   // the big band is whole rounds but for a few tiles, whose slots the short tiles take
+        const double cb = bd->first_small / 512.0 * 128.0 + rounds((long)bd->mt_small * nt) * 64.0 / 0.93;
+        if (cb < 0.98 * best) pick = 7;   // within 2 % the plain plans measure as fast or faster (feature convolutions 5 / 6: 537 vs 532, 277 vs 271 us)
+    }
+    return pick;
 }
 
 hipError_t launch_conv_gemm_ring(const ConvParams &p_in, int variant, hipStream_t stream) {
@@ -288,8 +335,8 @@ hipError_t launch_conv_gemm_ring(const ConvParams &p_in, int variant, hipStream_
         if (hipGetDevice(&dev) == hipSuccess) p.zero = skinny_zero_buffer(dev);
     }
     if (!p.zero || !conv_gemm_ring_takes(p)) return hipErrorInvalidValue;
-    if (variant == 0) variant = conv_gemm_ring_pick(p);
-    if (variant == 10) variant = conv_gemm_ring_pick(p) == 3 ? 6 : 5;   // the pick, tiles dealt to the XCDs
+    if (variant == 0) variant = conv_gemm_ring_pick(p, nullptr);
+    if (variant == 10) variant = conv_gemm_ring_pick(p, nullptr) == 3 ? 6 : 5;   // the pick (without bands), tiles dealt to the XCDs
     const dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.ngroups);
     auto dealt = [&](int bm) { return dim3(8 * (unsigned)(((long)((p.M + bm - 1) / bm) * grid.y + 7) / 8), 1, grid.z); };
     switch (variant) {

@@ -101,8 +101,9 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const Co
 // the LDS-DMA ring engine (conv_gemm_ring.hip); variant 1 = 128 x 128 on 4 waves of 64 x 64, 9 = 128 x 128 on 8 waves of 32 x 64, 3 = 96 x 128 on 4 waves
 // of 96 x 32 (tile ids 31 / 39 / 33), 0 = 9 or 3 by the layer's tile count (conv_gemm_ring_pick)
 hipError_t launch_conv_gemm_ring(const ConvParams &p, int variant, hipStream_t stream);
+hipError_t launch_conv_gemm_ring_banded(const ConvParams &p, const ConvBands &bd, hipStream_t stream);   // tile id 37: bands (plan_bands) + dealt tiles
 bool conv_gemm_ring_takes(const ConvParams &p);   // host: every segment a multiple of the 32-deep stage
-int conv_gemm_ring_pick(const ConvParams &p);      // host: 9 or 3
+int conv_gemm_ring_pick(const ConvParams &p, const ConvBands *bd);   // host: the plan by tile count: 9 (128 x 128), 3 (96 x 128) or, if `bd` is given, 7 (bands)
 
 // grouped many-tap convolution with 48 channels per group (conv_taps48.hip: the wav2vec2 positional convolution); tile id 48
 hipError_t launch_conv_taps48(const ConvParams &p, hipStream_t stream);

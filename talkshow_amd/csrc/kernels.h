@@ -59,9 +59,10 @@ struct ConvBands {
 };
 
 bool conv_gemm_band_plan(const ConvParams &p, ConvBands &bd);   // host only: the plan launch_conv_gemm(p, 0, ...) would use
+bool conv_gemm_plan_bands(const ConvParams &p, ConvBands &bd);  // host only: the bands of a layer given to 128 x 128 tiles (false: none — under one round, or whole rounds)
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 (BK 64), 6 = 160x128, 7 = 96x128 (for tuning / tests);
 // 31 / 39 / 33 = the LDS-DMA ring engine's 128x128 tile with 4 / 8 waves, its 96x128 tile (conv_gemm_ring.hip); 35 / 36 = 39 / 33 with the
-// tiles dealt to the XCDs in operand-sharing blocks; 48 = conv_taps48.hip (batched problems of 48-channel taps only)
+// tiles dealt to the XCDs in operand-sharing blocks, 37 = bands + dealt tiles; 48 = conv_taps48.hip (batched problems of 48-channel taps only)
 hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream);
 // the same convolution on the bf16 matrix cores with fp32 operands split into `planes` bf16 terms (2: three products, ~2^-16;
 // 3: six products, fp32 grade) — conv_gemm_split.hip; an opt-in plan for tolerance-only GEMMs (the face generator)
@@ -205,6 +206,7 @@ struct Knobs {
     bool vq_lds = true;         // TS_VQ_LDS=0: the codebook search reads code rows from L2 per thread instead of LDS-staged tiles (tests, A/B)
     int conv_ring = 9;          // TS_CONV_RING=0|1|3|8|9: single-problem layers that take 128 x 128 tiles on conv_gemm.hip (0) / forced onto the ring engine's 128 x 128 tile with 4 (1) or 8 (8) waves or its 96 x 128 tile (3) / (9, default) 128 x 128 on 8 waves or 96 x 128 by tile count
     bool conv_taps48 = true;    // TS_CONV_TAPS48=0: the face generator's grouped positional conv as 64-channel windows on conv_gemm_f32's tiles instead of conv_taps48.hip (A/B, tests)
+    bool conv_ring_paired = true;    // TS_CONV_RING_PAIRED=0: paired layers (two problems per launch: body + hands) on conv_gemm.hip's banded launch instead of the ring engine (A/B, tests)
     bool conv_deal = true;      // TS_CONV_DEAL=0: the ring engine's tiles as a plain (row tiles, column tiles) grid instead of dealt to the XCDs in operand-sharing blocks (A/B, tests)
     int split_xcd = 8;          // TS_SPLIT_XCD: column-group width of conv_gemm_split's XCD-aware tile order (0: plain 2-D tile grid)
     bool prof_log = false;      // TS_PROF_LOG=1: one stderr line per conv launch while ts_prof is enabled

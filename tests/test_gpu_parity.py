@@ -91,7 +91,7 @@ def test_conv_tile_shapes_agree(hip):
     ref = np.where(ref >= 0, ref, 0.2 * ref).astype(np.float32)
     xd, wd, bd = dev(x), dev(w), dev(b)
     outs = {}
-    for tile in (1, 2, 3, 4, 5, 6, 7, 31, 33, 39, 35, 36, 0):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 31, 33, 39, 35, 36, 37, 0):
         out = torch.full((B, L, Cout), float("nan"), dtype=torch.float32, device="cuda")
         _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, tile, 1,
                                           _lib.dptr(out), None, None))
@@ -181,14 +181,14 @@ def test_conv_banded_launch_matches_plain_tiles(hip):
     b[:Cout] = rng.standard_normal(Cout).astype(np.float32)
     xd, wd, bd = dev(x), dev(w), dev(b)
     outs = {}
-    for tile in (0, 1, 2, 31, 33, 39, 35, 36):   # 31 / 39 / 33: the ring engine on a plain grid of 128 x 128 / 96 x 128 tiles; 35 / 36: tiles dealt to the XCDs (604 / 804 tiles: padding workgroups idle)
+    for tile in (0, 1, 2, 31, 33, 39, 35, 36, 37):   # 31 / 39 / 33: the ring engine on a plain grid of 128 x 128 / 96 x 128 tiles; 35 / 36: tiles dealt to the XCDs (604 / 804 tiles: padding workgroups idle); 37: bands + dealt tiles
         out = torch.full((B, L, Cout), float("nan"), dtype=torch.float32, device="cuda")
         _lib.check(lib.ts_op_conv1d_timed(ctx, _lib.dptr(xd), B, L, Cin, _lib.dptr(wd), _lib.dptr(bd), Cout, K, tile, 1,
                                           _lib.dptr(out), None, None))
         torch.cuda.synchronize()
         outs[tile] = out.cpu().numpy()
     assert np.isfinite(outs[0]).all()
-    for tile in (1, 2, 31, 33, 39, 35, 36):
+    for tile in (1, 2, 31, 33, 39, 35, 36, 37):
         assert np.array_equal(outs[0], outs[tile]), f"tile {tile} differs from the banded launch"
     rows = rng.integers(0, L, 64)
     xp = np.pad(x, ((0, 0), (1, 1), (0, 0)))
@@ -1121,17 +1121,17 @@ def test_wav_in_code_stability(hip, tmp_path):
                                  {"TS_SKINNY_TILED": "0", "TS_WITH_CLIPS": "1"}, {"TS_PIX_DEFER_P": "0", "TS_WITH_CLIPS": "1"},
                                  {"TS_PIX_DEFER_P": "1", "TS_WITH_CLIPS": "1"}, {"TS_SKINNY_WIDE_MIN": "0", "TS_WITH_CLIPS": "1"},
                                  {"TS_SKINNY_WIDE_MIN": "1", "TS_WITH_CLIPS": "1"}, {"TS_VQ_LDS": "0", "TS_CONV_RING": "0", "TS_WITH_VQ": "1"},
-                                 {"TS_CONV_DEAL": "0", "TS_CONV_TAPS48": "0", "TS_WITH_VQ": "1"}],
+                                 {"TS_CONV_DEAL": "0", "TS_CONV_TAPS48": "0", "TS_WITH_VQ": "1"}, {"TS_CONV_RING_PAIRED": "0", "TS_WITH_VQ": "1", "TS_WITH_CLIPS": "1"}],
                          ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
                               "row_major_operands", "projections_in_column0", "projections_in_column1",
                               "split_k_kernels_only", "wide_kernel_everywhere", "per_thread_vq_search_and_register_staged_conv",
-                              "ring_conv_on_a_plain_grid_and_padded_positional_conv"])
+                              "ring_conv_on_a_plain_grid_and_padded_positional_conv", "paired_layers_on_the_register_staged_banded_launch"])
 def test_alternate_kernel_paths(hip, env):
     """The PixelCNN chain has a fast descriptor-driven kernel + hipGraph replay and generic fallbacks (other shapes, eager
     launches, the 32-column kernel), row-major instead of tiled operands, two placements of the next-row projections, and
     the 64 x 64 wide kernel that coalesced passes use for launches of >= 160 workgroups (forced off / forced onto every
     launch of >= 64 clips here, small head / column-1 launches included); the codebook search has an LDS-staged and a per-thread
-    form, conv_gemm_f32 a register-staged and an LDS-DMA engine (the last entry forces the older of each).  The knobs are read once per process, so the
+    form, conv_gemm_f32 a register-staged and an LDS-DMA engine, the latter with its tiles on a plain grid or dealt to the XCDs, the positional conv a padded and an unpadded kernel (the last entries force the older of each).  The knobs are read once per process, so the
     golden-vector tests are re-run in a child process with each path forced: all must stay bit-exact on the codes."""
     import subprocess
     import sys

@@ -320,17 +320,21 @@ def test_pixelcnn_audio_map_columns_must_be_copies():
 
 
 def test_conv_ring_tile_choice_by_tile_count():
-    """The ring engine's tile height for a single-problem layer (host-only): rounds of 512 resident workgroups, a last round at most
-    half full costs half a round, a 96-row tile 5 % more per flop.  The wav2vec2 blocks at batch 64 x 300 frames: out-proj / FFN2 (N = 768:
-    900 tiles of 128 rows = 1.76 rounds -> 2; 1 200 of 96 rows -> 2.5 x 0.75) take 96-row tiles; FFN1 (7.03 -> 7.5 against 9.375 -> 9.5 x
-    0.75: a tie before the 5 %), QKV (5.27 -> 5.5 against 7.03 -> 7.5 x 0.75), exact multiples of a round and the long feature
-    convolutions keep 128."""
+    """The ring engine's tile plan for a layer (host-only): rounds of 512 resident workgroups, a last round at most half full costs half a
+    round; 128-row tiles, 96-row tiles (5 % more per flop) or bands (128-row tiles for the whole rounds + 64-row tiles, 7 % more per flop, for
+    the rest; reported as 64).  The wav2vec2 blocks at batch 64 x 300 frames: out-proj / FFN2 (N = 768: 900 tiles of 128 rows = 1.76 rounds
+    -> 2; 1 200 of 96 rows -> 2.5 x 0.75) take 96-row tiles; FFN1 (7.03 rounds -> 6.98 + half a short one) and the paired body + hand layers of
+    a 256-clip pass (2 400 tiles = 4.69 rounds -> 4 + 1.5 short ones) take bands; QKV (5.27 -> 5.5), exact multiples of a round and the long
+    feature convolutions (bands within 2 %) keep 128."""
     from talkshow_amd import _lib
     lib = _lib.load()
     assert lib.ts_debug_conv_ring_pick(19200, 768, 1) == 96
-    assert lib.ts_debug_conv_ring_pick(19200, 3072, 1) == 128
+    assert lib.ts_debug_conv_ring_pick(19200, 3072, 1) == 64
     assert lib.ts_debug_conv_ring_pick(255936, 512, 1) == 128 and lib.ts_debug_conv_ring_pick(511936, 512, 1) == 128
+    assert lib.ts_debug_conv_ring_pick(1023936, 512, 1) == 128 and lib.ts_debug_conv_ring_pick(63936, 512, 1) == 128
     assert lib.ts_debug_conv_ring_pick(19200, 2304, 1) == 128
     assert lib.ts_debug_conv_ring_pick(16384, 1024, 1) == 128          # 1 024 tiles: two whole rounds
     assert lib.ts_debug_conv_ring_pick(8192, 1024, 1) == 128
+    for M, N, G in ((19200, 1024, 2), (38400, 512, 2), (76800, 256, 2), (19200, 512, 4)):   # the paired layers of the VQ stacks at 256 clips
+        assert lib.ts_debug_conv_ring_pick(M, N, G) == 64
     assert lib.ts_debug_conv_ring_pick(0, 64, 1) == -1

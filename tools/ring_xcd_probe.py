@@ -17,7 +17,7 @@ lib = _lib.load()
 ctx = _lib.context(0)
 ROUNDS = int(os.environ.get("TS_ROUNDS", "3"))
 TILES = [int(t) for t in os.environ.get("TS_TILES", "39,35,33,36").split(",")]
-NAMES = {39: "plain 128", 35: "dealt 128", 33: "plain 96", 36: "dealt 96", 1: "reg 128", 0: "prod"}
+NAMES = {39: "plain 128", 35: "dealt 128", 33: "plain 96", 36: "dealt 96", 37: "bands+dealt", 1: "reg 128", 0: "prod"}
 # (B, Lin, Cin, Cout, K, stride, tag); stride 0 = the padded stride-1 entry
 SHAPES = [
     (64, 31999, 512, 512, 3, 2, "feat conv1"), (64, 15999, 512, 512, 3, 2, "feat conv2"), (64, 7999, 512, 512, 3, 2, "feat conv3"),
