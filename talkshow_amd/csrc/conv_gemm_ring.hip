@@ -2,10 +2,10 @@
 // taps / strides, same MFMA, same k order: BIT-IDENTICAL outputs), with the operand path rebuilt around direct global -> LDS
 // loads (global_load_lds_dwordx4) instead of global -> VGPR -> ds_write, and 8 waves per 128 x 128 tile.
 //
-// Replaces the same PyTorch ops as conv_gemm.hip; it takes the single-problem layers that get 128 x 128 tiles — the plain-GEMM
-// layers of the face generator: the wav2vec2 encoder blocks' QKV / out-proj / FFN1 / FFN2 (reference: nets/spg/wav2vec.py:76-143,
-// HF Wav2Vec2EncoderLayer), its feature convolutions and heads (nets/spg/s2g_face.py:196-224).  The paired body + hand layers of
-// nets/spg/vqvae_modules.py:87-212 stay on conv_gemm.hip's banded launch, which measures faster on them (profiles/r05_notes/).
+// Replaces the same PyTorch ops as conv_gemm.hip; it takes every layer that gets 128 x 128 tiles — the plain-GEMM layers of the face
+// generator: the wav2vec2 encoder blocks' QKV / out-proj / FFN1 / FFN2 (reference: nets/spg/wav2vec.py:76-143, HF
+// Wav2Vec2EncoderLayer), its feature convolutions and heads (nets/spg/s2g_face.py:196-224) — and the paired body + hand layers of
+// nets/spg/vqvae_modules.py:87-212 (two problems per launch), for which it has conv_gemm.hip's band plan (conv_ring_banded_kernel).
 //
 // Mapping to CDNA4:
 //   * a stage = 32 consecutive k of the tile's 128 activation rows and 128 weight rows, row-major in LDS with a row pitch of 128
