@@ -41,6 +41,7 @@ const Knobs &knobs() {
         v.skinny_shape = num("TS_SKINNY_SHAPE", 0);
         v.skinny_trace = num("TS_SKINNY_TRACE", 0);
         v.wide_ablate = num("TS_SKINNY_WIDE_ABLATE", 0);
+        v.wide_pair = num("TS_SKINNY_WIDE_PAIR", 1) != 0;
         return v;
     }();
     return k;

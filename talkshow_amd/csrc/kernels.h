@@ -218,6 +218,7 @@ struct Knobs {
     int wide_min = 160;         // TS_SKINNY_WIDE_MIN: workgroups from which a coalesced launch takes the wide kernel (0 never, 1 always)
     int skinny_shape = 0;       // TS_SKINNY_SHAPE=11|21|22|42: forced split-K tile shape
     int skinny_trace = 0;       // TS_SKINNY_TRACE=1: in-kernel clock stamps (tools/skinny_trace.py, tools/wide_trace.py)
+    bool wide_pair = true;      // TS_SKINNY_WIDE_PAIR=0: the wide kernel's tiles enumerated column-major instead of (clip-block pair, column tile, block of the pair) (A/B, tests)
     int wide_ablate = 0;        // TS_SKINNY_WIDE_ABLATE=2|4 (trace builds): no loads / no MFMAs in the wide kernel
 };
 const Knobs &knobs();

@@ -825,7 +825,7 @@ hipError_t launch_skinny_batch(const SkinnyParams *const *ps, int n, hipStream_t
                         if (wide) {
                             db.start[6] = db.start[7] = 0;
                             const int wide_abl = knobs().wide_ablate;
-                            db.start[0] = g_trace_host ? wide_abl : 0;   // trace builds only: 2 = no loads, 4 = no MFMAs (problem 0 always starts at workgroup 0)
+                            db.start[0] = (g_trace_host ? wide_abl : 0) | (knobs().wide_pair ? 8 : 0);   // trace builds only: 2 = no loads, 4 = no MFMAs (problem 0 always starts at workgroup 0)
                             if (g_trace_host) {
                                 const uint64_t rec = (uint64_t)(uintptr_t)(g_trace_host + (size_t)(g_trace_seq++ % TRACE_LAUNCHES) * TRACE_WGS * TRACE_REC);
                                 db.start[6] = (int)(uint32_t)rec;
