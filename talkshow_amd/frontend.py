@@ -224,6 +224,84 @@ def mfcc_float64(wave, sample_rate, n_mfcc=64, n_fft=2048, hop_length=734, n_mel
     return np.ascontiguousarray((db @ create_dct(n_mfcc, n_mels).astype(np.float64)).T)
 
 
+# ---- onset times (`utils.py:200-201`: librosa.onset.onset_detect(y, sr=16000, units='time'); the beat-consistency score of
+# scripts/test_body.py:173 reads them) -----------------------------------------------------------------------------------------
+def _slaney_hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    lin = f / (200.0 / 3.0)
+    log = 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) / (math.log(6.4) / 27.0)
+    return np.where(f >= 1000.0, log, lin)
+
+
+def _slaney_mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    return np.where(m >= 15.0, 1000.0 * np.exp((math.log(6.4) / 27.0) * (m - 15.0)), m * (200.0 / 3.0))
+
+
+def slaney_mel_filters(sr, n_fft, n_mels=128, fmin=0.0, fmax=None):
+    """librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=False, norm='slaney') as published: triangles on the Slaney mel scale (linear
+    below 1 kHz, logarithmic above), each scaled by 2 / (its band edges' distance in Hz).  -> (n_mels, n_fft // 2 + 1)."""
+    fmax = sr / 2.0 if fmax is None else fmax
+    fft_f = np.linspace(0.0, sr / 2.0, n_fft // 2 + 1)
+    mel_f = _slaney_mel_to_hz(np.linspace(_slaney_hz_to_mel(fmin), _slaney_hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fft_f[None, :]
+    lower, upper = -ramps[:-2] / fdiff[:-1, None], ramps[2:] / fdiff[1:, None]
+    w = np.maximum(0.0, np.minimum(lower, upper))
+    return (w * (2.0 / (mel_f[2:] - mel_f[:-2]))[:, None]).astype(F32)
+
+
+def onset_strength(wave, sr, n_fft=2048, hop_length=512, n_mels=128):
+    """librosa.onset.onset_strength(y, sr) with its defaults as published: mel power spectrogram (Slaney filters up to sr / 2, Hann
+    window, centred frames) in dB (top_db 80), first difference along time, half-wave rectified, mean over the bands, shifted by
+    lag + n_fft // (2 hop) frames so that a frame's value describes the frame it is reported at.  -> (T,)"""
+    power = power_spectrogram(wave, n_fft, hop_length)                              # (T, n_fft // 2 + 1), reflect-padded frames
+    mel = power @ slaney_mel_filters(sr, n_fft, n_mels).T                           # (T, n_mels)
+    db = 10.0 * np.log10(np.maximum(mel, 1e-10))
+    db = np.maximum(db, db.max() - 80.0)
+    env = np.maximum(0.0, db[1:] - db[:-1]).mean(axis=1)
+    pad = 1 + n_fft // (2 * hop_length)
+    return np.concatenate([np.zeros(pad), env])[:power.shape[0]]
+
+
+def peak_pick(x, pre_max, post_max, pre_avg, post_avg, delta, wait):
+    """librosa.util.peak_pick as published: x[n] is a peak if it is the maximum of x[n - pre_max : n + post_max], at least
+    mean(x[n - pre_avg : n + post_avg]) + delta, and more than `wait` samples after the previous peak."""
+    x = np.asarray(x, dtype=np.float64)
+    n_all, peaks, last = x.shape[0], [], -np.inf
+    for n in range(n_all):
+        if x[n] < x[max(n - pre_max, 0):min(n + post_max, n_all)].max():
+            continue
+        if x[n] < x[max(n - pre_avg, 0):min(n + post_avg, n_all)].mean() + delta:
+            continue
+        if n > last + wait:
+            peaks.append(n)
+            last = n
+    return np.asarray(peaks, dtype=np.int64)
+
+
+def onset_times(wave, sr=16000, hop_length=512):
+    """Onset times in seconds of a mono waveform: `librosa.onset.onset_detect(y=wave, sr=sr, units='time')` — by librosa ITSELF when
+    it is importable (the reference's pin is librosa~=0.9.2; this image has none), else by the restatement above of its published
+    algorithm (onset strength -> normalised to [0, 1] -> peak picking with the 30 ms / 100 ms / 0.07 defaults).  PARITY UNPINNED for
+    the restatement: no librosa here to compare with and no fixture in the reference; it exists so that the reference's evaluation
+    loop (scripts/test_body.py:173, beat consistency) runs without the package."""
+    wave = np.asarray(wave, dtype=F32).reshape(-1)
+    try:
+        import librosa
+        return np.asarray(librosa.onset.onset_detect(y=wave, sr=sr, units='time'), dtype=np.float64)
+    except ImportError:
+        pass
+    env = onset_strength(wave, sr, hop_length=hop_length)
+    env = env - env.min()
+    if not env.any():
+        return np.zeros(0, dtype=np.float64)
+    env = env / (env.max() + np.finfo(np.float64).tiny)
+    peaks = peak_pick(env, pre_max=int(0.03 * sr // hop_length), post_max=int(0.00 * sr // hop_length + 1), pre_avg=int(0.10 * sr // hop_length),
+                      post_avg=int(0.10 * sr // hop_length + 1), delta=0.07, wait=int(0.03 * sr // hop_length))
+    return peaks.astype(np.float64) * hop_length / sr
+
+
 def _hop(fps):
     if fps == 15:
         return 1467
@@ -270,7 +348,8 @@ def get_mfcc_ta(aud_fn, eps=1e-6, fps=15, smlpx=False, sr=16000, n_mfcc=64, win_
     wav files: resample + MFCC run on the GPU (ts_mfcc_forward) when a HIP device is present, else on the host in numpy
     (`host=True` forces the numpy path, which is also the checker of the device path in tests/).  With a processor handed in
     (`am is not None`) the reference switches on `encoder_choice` (`utils.py:193-202`): 'faceformer' -> `get_wav16`,
-    'meshtalk' -> scaled samples, 'onset' -> NotImplementedError here, anything else -> the MFCC features as without `am`."""
+    'meshtalk' -> scaled samples, 'onset' -> onset times in seconds (K, 1) (`onset_times`: librosa itself when it is installed, else a
+    restatement), anything else -> the MFCC features as without `am`."""
     if am is not None and encoder_choice in ('faceformer', 'meshtalk', 'onset'):
         # the reference's `am is not None` branch (`utils.py:193-202`): librosa.load(sr=16000), then a switch on encoder_choice
         if encoder_choice == 'faceformer':                      # raw 16 kHz samples (N, 1): the face generator's input
@@ -278,8 +357,7 @@ def get_mfcc_ta(aud_fn, eps=1e-6, fps=15, smlpx=False, sr=16000, n_mfcc=64, win_
         if encoder_choice == 'meshtalk':                        # `0.01 * speech_array / np.mean(np.abs(speech_array))`, shape (N,)
             x = get_wav16(aud_fn, host=host)[:, 0]
             return (F32(0.01) * x / np.mean(np.abs(x))).astype(F32)
-        raise NotImplementedError("encoder_choice='onset' needs librosa.onset.onset_detect (third-party, absent; no shipped "
-                                  "config uses it)")
+        return onset_times(get_wav16(aud_fn, host=host)[:, 0], 16000).reshape(-1, 1)   # `utils.py:200-201`, used by test_body.py:173
     feat = _features_from_any(aud_fn)
     if feat is None and type in ('mel', 'mel_mul'):
         # the two other feature types of `utils.py:178-191` (no shipped config asks for them: they run on the host, in numpy)

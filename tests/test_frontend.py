@@ -209,7 +209,7 @@ def test_get_wav16_resamples_other_rates(tmp_path):
 
 def test_get_mfcc_ta_encoder_choice_switch(tmp_path):
     """`get_mfcc_ta(am=<processor>, encoder_choice=...)` (`data_utils/utils.py:193-202`): 'faceformer' -> the raw 16 kHz samples
-    (N, 1), 'meshtalk' -> samples scaled to mean |x| = 0.01, 'onset' -> refused by name (librosa.onset is absent), any other
+    (N, 1), 'meshtalk' -> samples scaled to mean |x| = 0.01, 'onset' -> onset times (K, 1), any other
     value -> the MFCC features exactly as without `am`; without `am` the argument has no effect, as in the reference."""
     from scipy.io import wavfile
     x = (0.2 * np.sin(2 * np.pi * 250 * np.arange(16000) / 16000.0)).astype(np.float32)
@@ -220,8 +220,8 @@ def test_get_mfcc_ta_encoder_choice_switch(tmp_path):
     assert w.shape == (16000, 1) and np.array_equal(w[:, 0], x)
     m = fe.get_mfcc_ta(p, sr=16000, fps=30, am=am, encoder_choice='meshtalk', host=True)
     assert m.shape == (16000,) and abs(float(np.mean(np.abs(m))) - 0.01) < 1e-6
-    with pytest.raises(NotImplementedError, match="onset"):
-        fe.get_mfcc_ta(p, sr=16000, fps=30, am=am, encoder_choice='onset', host=True)
+    on = fe.get_mfcc_ta(p, sr=16000, fps=30, am=am, encoder_choice='onset', host=True)
+    assert on.ndim == 2 and on.shape[1] == 1                                          # onset times (s); test_onset_times_restatement
     base = fe.get_mfcc_ta(p, sr=22000, fps=30, host=True)
     assert base.shape[1] == 64
     for kw in (dict(am=am), dict(am=am, encoder_choice='mfcc'), dict(encoder_choice='faceformer')):
@@ -267,3 +267,31 @@ def test_kaiser_best_interpolation_against_its_continuous_definition(orig, n):
     want = h @ x.astype(np.float64)
     np.testing.assert_allclose(y[:n_out], want, atol=3e-5, rtol=0)
     assert y.shape[0] == math.ceil(n * ratio) and np.all(y[n_out:] == 0)       # librosa's fix_length zero-fills the tail
+
+
+def test_onset_times_restatement(tmp_path):
+    """`get_mfcc_ta(..., am=<processor>, encoder_choice='onset')` (`utils.py:200-201`, read by scripts/test_body.py:173): onset times in
+    seconds, (K, 1).  librosa is absent here, so this runs the restatement of its published algorithm (PARITY UNPINNED, see the
+    docstring of `frontend.onset_times`); what can be checked without the package: the Slaney filters integrate to one, the onset
+    envelope is zero for a constant signal, every tone burst of a synthetic clip is found within two frames, silence gives no onset."""
+    from scipy.io import wavfile
+    from transformers import audio_utils as au
+    w = fe.slaney_mel_filters(16000, 2048)
+    assert w.shape == (128, 1025) and np.allclose(w.sum(1) * (16000 / 2048), 1.0, atol=2e-2) and (w >= 0).all()
+    hf = au.mel_filter_bank(1025, 128, 0.0, 8000.0, 16000, norm="slaney", mel_scale="slaney")      # HF's port of librosa.filters.mel: this stage IS pinned
+    np.testing.assert_allclose(w.T, hf, atol=1e-7, rtol=0)
+    assert fe.onset_times(np.zeros(16000, np.float32)).shape == (0,)
+    rng = np.random.default_rng(3)
+    beats = np.asarray([0.5, 1.2, 2.0, 2.9, 3.7, 4.4])
+    tt = np.arange(4000) / 16000.0
+    x = 0.001 * rng.standard_normal(5 * 16000)
+    for j, b0 in enumerate(beats):
+        x[int(b0 * 16000):int(b0 * 16000) + 4000] += 0.5 * np.sin(2 * np.pi * (300 + 60 * j) * tt) * np.exp(-12 * tt)
+    p = str(tmp_path / "bursts.wav")
+    wavfile.write(p, 16000, x.astype(np.float32))
+    on = fe.get_mfcc_ta(p, fps=30, sr=16000, am="processor", encoder_choice="onset", host=True)
+    assert on.ndim == 2 and on.shape[1] == 1 and on.dtype == np.float64
+    assert np.abs(on[:, 0][None, :] - beats[:, None]).min(axis=1).max() < 0.08      # every burst, within two frames + a hop (32 ms each)
+    assert (np.diff(on[:, 0]) > 0).all() and on.min() >= 0 and on.max() < 5.0
+    env = fe.onset_strength(x.astype(np.float32), 16000)
+    assert env.shape == (x.size // 512 + 1,) and (env >= 0).all() and env[:3].max() == 0.0
