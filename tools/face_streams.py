@@ -30,7 +30,8 @@ def measure(B, nstreams, rounds=4):
     return dt, outs
 ref_wav, ref_ids = data(64, 3000)
 ref = m.run(ref_wav, ref_ids, T); torch.cuda.synchronize()
-for B, ns in ((64, 1), (64, 2), (64, 3), (32, 2), (32, 4), (64, 1)):
+CASES = ((64, 1), (64, 2), (64, 3), (32, 2), (32, 4), (64, 1)) if not os.environ.get("TS_CASES") else tuple(tuple(int(v) for v in c.split("x")) for c in os.environ["TS_CASES"].split(","))
+for B, ns in CASES:
     dt, outs = measure(B, ns)
     clips = B * ns
     same = torch.equal(outs[0], ref[:B]) if B <= 64 else None
