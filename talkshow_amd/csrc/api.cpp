@@ -197,6 +197,24 @@ int ts_op_conv1d(ts_ctx *ctx, const float *x, int B, int Lin, int Cin, const flo
     return 0;
 }
 
+// one warm-up launch, then `iters` launches of the layer between two HIP events on `s`: *ms_out = mean launch duration (ms)
+static int time_conv_launches(const ts::ConvParams &p, int tile, int iters, float *ms_out, hipStream_t s) {
+    hipEvent_t a, b;
+    TS_HIP(hipEventCreate(&a));
+    TS_HIP(hipEventCreate(&b));
+    TS_HIP(ts::launch_conv_gemm(p, tile, s));
+    TS_HIP(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) TS_HIP(ts::launch_conv_gemm(p, tile, s));
+    TS_HIP(hipEventRecord(b, s));
+    TS_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    TS_HIP(hipEventElapsedTime(&ms, a, b));
+    if (ms_out) *ms_out = ms / (iters > 0 ? iters : 1);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return 0;
+}
+
 // Tuning / roofline entry (not part of the drop-in surface): a stride-1 conv layer (K = 1 or 3, Cin % 32 == 0) with
 // weights ALREADY packed on the device as [round128(Cout)][K*Cin] (tap-major), launched `iters` times between two HIP
 // events on `stream` with a chosen tile shape (0 = the heuristic used in production).  ms_out = mean launch duration.
@@ -223,20 +241,7 @@ int ts_op_conv1d_timed(ts_ctx *ctx, const float *x, int B, int Lin, int Cin, con
     p.g[0].out = out;
     p.g[0].nseg = K;
     for (int k = 0; k < K; ++k) p.g[0].seg[k] = ConvSeg{K == 1 ? 0 : k - 1, 0, Cin};
-    hipEvent_t a, b;
-    TS_HIP(hipEventCreate(&a));
-    TS_HIP(hipEventCreate(&b));
-    TS_HIP(launch_conv_gemm(p, tile, s));   // warm-up
-    TS_HIP(hipEventRecord(a, s));
-    for (int i = 0; i < iters; ++i) TS_HIP(launch_conv_gemm(p, tile, s));
-    TS_HIP(hipEventRecord(b, s));
-    TS_HIP(hipEventSynchronize(b));
-    float ms = 0.f;
-    TS_HIP(hipEventElapsedTime(&ms, a, b));
-    if (ms_out) *ms_out = ms / (iters > 0 ? iters : 1);
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    return 0;
+    return time_conv_launches(p, tile, iters, ms_out, s);
 }
 
 // the same for a strided convolution without padding (the wav2vec2 feature convolutions: out[t] = sum_k W_k x[stride t + k]);
@@ -265,20 +270,7 @@ int ts_op_conv1d_strided_timed(ts_ctx *ctx, const float *x, int B, int Lin, int 
     p.g[0].out = out;
     p.g[0].nseg = K;
     for (int k = 0; k < K; ++k) p.g[0].seg[k] = ConvSeg{k, 0, Cin};
-    hipEvent_t a, b;
-    TS_HIP(hipEventCreate(&a));
-    TS_HIP(hipEventCreate(&b));
-    TS_HIP(launch_conv_gemm(p, tile, s));   // warm-up
-    TS_HIP(hipEventRecord(a, s));
-    for (int i = 0; i < iters; ++i) TS_HIP(launch_conv_gemm(p, tile, s));
-    TS_HIP(hipEventRecord(b, s));
-    TS_HIP(hipEventSynchronize(b));
-    float ms = 0.f;
-    TS_HIP(hipEventElapsedTime(&ms, a, b));
-    if (ms_out) *ms_out = ms / (iters > 0 ? iters : 1);
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    return 0;
+    return time_conv_launches(p, tile, iters, ms_out, s);
 }
 
 // grouped many-tap convolution, 48 channels per group in and out (conv_taps48.hip: the wav2vec2 positional conv): x, res, out
@@ -309,20 +301,7 @@ int ts_op_conv_taps48_timed(ts_ctx *ctx, const float *x, int B, int T, int G, in
     p.g[0].out = out;
     p.g[0].nseg = 1;
     p.g[0].seg[0] = ConvSeg{-(ntap / 2), 0, 48, ntap};
-    hipEvent_t a, b;
-    TS_HIP(hipEventCreate(&a));
-    TS_HIP(hipEventCreate(&b));
-    TS_HIP(launch_conv_gemm(p, 48, s));   // warm-up
-    TS_HIP(hipEventRecord(a, s));
-    for (int i = 0; i < iters; ++i) TS_HIP(launch_conv_gemm(p, 48, s));
-    TS_HIP(hipEventRecord(b, s));
-    TS_HIP(hipEventSynchronize(b));
-    float ms = 0.f;
-    TS_HIP(hipEventElapsedTime(&ms, a, b));
-    if (ms_out) *ms_out = ms / (iters > 0 ? iters : 1);
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    return 0;
+    return time_conv_launches(p, 48, iters, ms_out, s);
 }
 
 int ts_debug_conv_ring_pick(int M, int N, int groups) {
