@@ -29,6 +29,7 @@ const Knobs &knobs() {
         v.conv_deal = num("TS_CONV_DEAL", 1) != 0;
         v.conv_ring_paired = num("TS_CONV_RING_PAIRED", 1) != 0;
         v.conv_taps48 = num("TS_CONV_TAPS48", 1) != 0;
+        v.w2v_moments = num("TS_W2V_MOMENTS", 1) != 0;
         v.vq_lds = num("TS_VQ_LDS", 1) != 0;
         v.split_xcd = num("TS_SPLIT_XCD", 8);
         v.prof_log = num("TS_PROF_LOG", 0) != 0;

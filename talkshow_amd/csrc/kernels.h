@@ -205,6 +205,7 @@ struct Knobs {
     bool conv_bands = true;     // TS_CONV_BANDS=0: big conv layers as one plain grid of 128 x 128 tiles
     bool vq_lds = true;         // TS_VQ_LDS=0: the codebook search reads code rows from L2 per thread instead of LDS-staged tiles (tests, A/B)
     int conv_ring = 9;          // TS_CONV_RING=0|1|3|8|9: single-problem layers that take 128 x 128 tiles on conv_gemm.hip (0) / forced onto the ring engine's 128 x 128 tile with 4 (1) or 8 (8) waves or its 96 x 128 tile (3) / (9, default) 128 x 128 on 8 waves or 96 x 128 by tile count
+    bool w2v_moments = true;    // TS_W2V_MOMENTS=0: conv0's GroupNorm statistics from a pass that computes the convolution (512 channels) instead of from the input's second moments (A/B, tests)
     bool conv_taps48 = true;    // TS_CONV_TAPS48=0: the face generator's grouped positional conv as 64-channel windows on conv_gemm_f32's tiles instead of conv_taps48.hip (A/B, tests)
     bool conv_ring_paired = true;    // TS_CONV_RING_PAIRED=0: paired layers (two problems per launch: body + hands) on conv_gemm.hip's banded launch instead of the ring engine (A/B, tests)
     bool conv_deal = true;      // TS_CONV_DEAL=0: the ring engine's tiles as a plain (row tiles, column tiles) grid instead of dealt to the XCDs in operand-sharing blocks (A/B, tests)

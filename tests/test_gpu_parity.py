@@ -1121,7 +1121,7 @@ def test_wav_in_code_stability(hip, tmp_path):
                                  {"TS_SKINNY_TILED": "0", "TS_WITH_CLIPS": "1"}, {"TS_PIX_DEFER_P": "0", "TS_WITH_CLIPS": "1"},
                                  {"TS_PIX_DEFER_P": "1", "TS_WITH_CLIPS": "1"}, {"TS_SKINNY_WIDE_MIN": "0", "TS_WITH_CLIPS": "1"},
                                  {"TS_SKINNY_WIDE_MIN": "1", "TS_SKINNY_WIDE_PAIR": "0", "TS_WITH_CLIPS": "1"}, {"TS_VQ_LDS": "0", "TS_CONV_RING": "0", "TS_WITH_VQ": "1"},
-                                 {"TS_CONV_DEAL": "0", "TS_CONV_TAPS48": "0", "TS_WITH_VQ": "1"}, {"TS_CONV_RING_PAIRED": "0", "TS_WITH_VQ": "1", "TS_WITH_CLIPS": "1"}],
+                                 {"TS_CONV_DEAL": "0", "TS_CONV_TAPS48": "0", "TS_W2V_MOMENTS": "0", "TS_WITH_VQ": "1"}, {"TS_CONV_RING_PAIRED": "0", "TS_WITH_VQ": "1", "TS_WITH_CLIPS": "1"}],
                          ids=["generic_skinny_kernel", "eager_launches", "skinny_32col_kernel", "tile_32x32", "tile_64x32",
                               "row_major_operands", "projections_in_column0", "projections_in_column1",
                               "split_k_kernels_only", "wide_kernel_everywhere_column_major", "per_thread_vq_search_and_register_staged_conv",
