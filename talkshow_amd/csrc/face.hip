@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void w2v_conv0_apply_kernel(const float *__res
 // R[k][k'] = sum_t x[5 t + k] x[5 t + k'] — 65 numbers per clip (10 + 55, R is symmetric) instead of 512 x 2, and one pass over the waveform that
 // does 65 products per frame instead of 5 120 MACs.  Products of two floats are exact in double and all sums run in double in a fixed order: the
 // statistics are those of the exact convolution (the fp32 rounding of y in the direct form moves them by ~1e-8 relative; tests bound the face
-// generator against the reference either way).  Statistics pass 0.47 -> 0.17 ms per face batch of 64 (`other kernels` 2.07 -> 1.77 ms). ----
-constexpr int C0_MB = 2048;                 // frames per block of the moments kernel
+// generator against the reference either way).  Statistics pass 0.47 -> 0.07 ms per face batch of 64 (56 + 9.5 + 4.7 us for the three kernels). ----
+constexpr int C0_MB = 1024;                 // frames per block of the moments kernel (20 KB of LDS: seven blocks per CU)
 constexpr int C0_NQ = 65;                   // S[0..9], then R[k][k'] for k <= k' row by row
 __global__ __launch_bounds__(256) void w2v_conv0_moments_kernel(const float *__restrict__ wav, int N, int L0, double *__restrict__ part) {
     __shared__ float sw[C0_MB * 5 + 16];
@@ -121,12 +121,22 @@ __global__ __launch_bounds__(256) void w2v_conv0_moments_kernel(const float *__r
             }
             k2 = k + r;
         }
-        double acc = 0.0;
-        for (int t = slice; t < nt; t += 3) {
-            const double a = (double)sw[t * 5 + k];
-            acc += k2 < 0 ? a : a * (double)sw[t * 5 + k2];
+        // eight independent partial sums: the loop is a chain of LDS round trips + one dependent double add otherwise (3 waves per SIMD)
+        const float *pa = sw + k, *pb = k2 < 0 ? nullptr : sw + k2;
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int t = slice;
+        for (; t + 21 < nt; t += 24) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                va[u] = pa[(t + 3 * u) * 5];
+                vb[u] = pb ? pb[(t + 3 * u) * 5] : 1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += (double)va[u] * (double)vb[u];
         }
-        red[slice][q] = acc;
+        for (; t < nt; t += 3) acc[0] += (double)pa[t * 5] * (pb ? (double)pb[t * 5] : 1.0);
+        red[slice][q] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
     __syncthreads();
     if (threadIdx.x < C0_NQ) part[((long)b * gridDim.x + blockIdx.x) * C0_NQ + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x];
