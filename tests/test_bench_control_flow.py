@@ -67,7 +67,7 @@ class StubJob:
 
     def extras(self, out):
         self._say("extras")
-        time.sleep(0.05)                                         # long enough that a rank waiting in a collective would show
+        time.sleep(0.5)                                          # long enough that a rank waiting in a collective would show, also on a busy host
         out["roofline"] = {"frac": 0.0}
 
 
@@ -117,7 +117,7 @@ def test_bench_contract_control_flow(tmp_path, world):
     ex = [e for e in logs[0] if e["what"] == "extras"][0]
     assert ex["group_alive"] is False
     for r in range(1, world):
-        assert outs[r]["end"] < outs[0]["end"] - 0.04, "a rank other than 0 was still around while rank 0 ran its extras"
+        assert outs[r]["end"] < outs[0]["end"] - 0.25, "a rank other than 0 was still around while rank 0 ran its extras"
 
 
 def _failing_worker(rank, world, port, tmp):
