@@ -14,7 +14,11 @@ import os
 import shutil
 import sys
 
+import numpy as np
 from scipy.io import wavfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+from talkshow_amd import frontend as fe  # noqa: E402   (host twin of librosa.load(sr=16000): the face input of the real-audio goldens)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
@@ -27,8 +31,13 @@ for name, frames in FRAMES.items():
     shutil.copyfile(src, dst)
     os.chmod(dst, 0o644)
     sr, a = wavfile.read(dst)
+    # the 16 kHz mono samples the face path reads (tests/golden/real_audio_face.npz stores their sha256): native for 1st-page.wav,
+    # the host twin of kaiser_best for the other two — written next to the recording, git-ignored like it
+    wav16 = fe.get_wav16(dst, host=True)[:, 0]
+    np.save(dst + ".wav16.npy", wav16)
     manifest[name] = {"sha256": hashlib.sha256(open(dst, "rb").read()).hexdigest(), "sample_rate": int(sr), "shape": list(a.shape),
                       "dtype": str(a.dtype), "seconds": a.shape[0] / sr, "frames_30fps": frames,
+                      "wav16_samples": int(wav16.shape[0]), "wav16_sha256": hashlib.sha256(wav16.tobytes()).hexdigest(),
                       "source": "yhw-yhw/TalkSHOW demo_audio/" + name}
 json.dump(manifest, open(os.path.join(HERE, "audio_manifest.json"), "w"), indent=1)
 print(json.dumps(manifest, indent=1))

@@ -95,6 +95,7 @@ def main():
 
     sys.path.insert(0, REPO)
     from talkshow_amd import synth
+    from talkshow_amd import frontend as fe          # the host twin of the third-party front-end (real-audio cases only)
     sys.path.remove(REPO)
     nets = import_reference()
     import torch
@@ -533,6 +534,80 @@ def main():
             outs["full_stand_" + tag] = np.stack(res[True])
         print("assemble_full:", {k: v.shape for k, v in outs.items()})
         save("assemble_full", body=body, **outs)
+
+    # ---- 7. REAL AUDIO: the reference's own demo recordings (demo_audio/{style,1st-page,french}.wav, the inputs of scripts/demo.py)
+    # through the reference's modules downstream of the third-party front-end (every other golden uses iid
+    # N(0, 20^2) feature rows / white noise).  Body: the float64 twin's MFCC rows (talkshow_amd/frontend.py::mfcc_float64 — the
+    # front-end is third-party code, its pin stays separate) cast to float32 are the INPUT; the reference's AudioEncoder, the greedy
+    # harness around GatedPixelCNN.forward and both VQVAE.decode calls (smplx_body_pixel.py:272-285) produce the expected values.
+    # Each recording runs under all four speaker ids (B = 4: 1 944 greedy decisions over the three).  Stored: rows, audio-encoder output,
+    # codes and top-2 margins of the four, poses of one (the id listed in RECS).  H = 75 / 96 / 72; about a minute on 8 cores.
+    AUDIO = os.path.join(HERE, "audio")
+    RECS = (("style.wav", 2), ("1st-page.wav", 0), ("french.wav", 3))                # (recording, speaker id)
+    if args.only == "real_audio_body" or (not args.only and os.environ.get("TS_GOLDEN_BIG")):
+        tmp = tempfile.mkdtemp(prefix="ts_golden_")
+        vq_path = os.path.join(tmp, "vq.pth")
+        torch.save({"generator": {"g_body": T(synth.vqvae_state_dict(seed=7, in_dim=39)),
+                                  "g_hand": T(synth.vqvae_state_dict(seed=7, in_dim=90, salt=1))}}, vq_path)
+        cfg = json.load(open(os.path.join(REF, "config/body_pixel.json")))
+        cfg["Model"]["vq_path"] = vq_path
+        from trainer.config import Object
+        w = quiet(nets.s2g_body_pixel, argparse.Namespace(gpu="cpu", infer=True), Object(cfg))
+        w.load_state_dict({"generator": T(synth.pixelcnn_state_dict(seed=7)), "audioencoder": T(synth.audioencoder_state_dict(seed=7))})
+        w.generator.eval(); w.g_body.eval(); w.g_hand.eval(); w.audioencoder.eval()
+        out = {}
+        for name, spk in RECS:
+            tag = name[:-4].replace("-", "_")
+            wave = fe._load_mono_resampled(os.path.join(REF, "demo_audio", name), 22000)
+            rows = fe.mfcc_float64(wave, 22000, hop_length=734).T.astype(np.float32)      # (T, 64): what get_mfcc_ta hands the wrapper
+            ids = np.arange(4, dtype=np.int64)                                            # the recording under every speaker id: B = 4
+            with torch.no_grad():
+                feat = w.audioencoder(torch.from_numpy(rows[None]).transpose(1, 2), frame_num=0)    # smplx_body_pixel.py:274
+                aud = feat.unsqueeze(-1).repeat(4, 1, 1, 2)                                   # `aud_feat[np.newaxis].repeat(B)` (:249)
+                H = aud.shape[2]
+                codes, step_logits = greedy_reference(w.generator, torch.from_numpy(ids), aud, H)
+                body, _ = w.g_body.decode(b=4, w=H, latents=codes[..., 0])
+                hand, _ = w.g_hand.decode(b=4, w=H, latents=codes[..., 1])
+                poses = torch.cat([body, hand], dim=1).transpose(1, 2)
+            m = margins(step_logits.numpy()).reshape(4, H, 2)
+            print(f"real_audio_body {name}: rows {rows.shape} |max| {np.abs(rows).max():.0f}  H {H}  aud_feat |max| {float(feat.abs().max()):.2f} "
+                  f"margin min/median {m.min():.2e} {np.median(m):.3f}  decisions under 1e-3: {int((m < 1e-3).sum())} of {m.size}  "
+                  f"uniq codes {codes.unique().numel()}  pose std {float(poses.std()):.3f}")
+            out.update({f"{tag}_rows": rows, f"{tag}_aud_feat": feat.permute(0, 2, 1).numpy()[0], f"{tag}_codes": codes.numpy().astype(np.int16),
+                        f"{tag}_margin": m.astype(np.float32), f"{tag}_pose_id": np.asarray(spk), f"{tag}_poses": poses.numpy()[spk]})
+        save("real_audio_body", **out)
+
+    # ---- 7b. the face on the recordings: the reference wrapper's `generate(wav[None, None], frame)` (smplx_face.py:221-238: zero id)
+    # and `infer_on_audio`-style one-hot id through `generator(...)`, frame = N * 30 // 16000 (smplx_face.py:203).  1st-page.wav is
+    # native 16 kHz mono: int16 / 32768, no third-party step at all.  style.wav / french.wav: the 16 kHz samples the host twin of
+    # librosa's kaiser_best produces (tests/golden/audio/<name>.wav16.npy, written by fetch_reference_audio.py; their sha256 is stored
+    # here) are the input — the resampler's own pin stays separate.  Hidden state: every 6th frame of the lerped wav2vec2 output.
+    if args.only == "real_audio_face" or (not args.only and os.environ.get("TS_GOLDEN_BIG")):
+        import hashlib
+        fcfg = json.load(open(os.path.join(REF, "config/face.json")))
+        from trainer.config import Object
+        w = quiet(nets.s2g_face, argparse.Namespace(gpu="cpu", infer=True), Object(fcfg))
+        w.load_state_dict({"generator": T(synth.face_state_dict(seed=7))})
+        w.generator.eval()
+        out = {}
+        for name, spk in RECS:
+            tag = name[:-4].replace("-", "_")
+            wav = fe.get_wav16(os.path.join(REF, "demo_audio", name), host=True)[:, 0]            # (N,) float32 at 16 kHz
+            side = os.path.join(AUDIO, name + ".wav16.npy")
+            if os.path.exists(side):
+                assert np.array_equal(np.load(side), wav), f"{side} is not what the host twin produces here"
+            frame = wav.shape[0] * 30 // 16000
+            x = torch.from_numpy(wav)[None, None, :]
+            with torch.no_grad():
+                gen = w.generate(x, frame)                                                      # zero id
+                idv = torch.zeros(1, 4); idv[0, spk] = 1.0
+                hot = w.generator(x, None, idv, time_steps=frame)[0]                            # one-hot id (infer_on_audio's branch)
+                hs = w.generator.audio_encoder(torch.from_numpy(wav)[None], frame_num=frame).last_hidden_state
+            print(f"real_audio_face {name}: N {wav.shape[0]} frame {frame} out std {float(gen.std()):.3f} hidden std {float(hs.std()):.3f} "
+                  f"|wav| max {np.abs(wav).max():.3f} rms {np.sqrt((wav.astype(np.float64) ** 2).mean()):.4f}")
+            out.update({f"{tag}_n": np.asarray([wav.shape[0], frame, spk]), f"{tag}_wav16_sha256": np.asarray(hashlib.sha256(wav.tobytes()).hexdigest()),
+                        f"{tag}_out_zero_id": gen.numpy()[0], f"{tag}_out_one_hot": hot.numpy()[0], f"{tag}_hidden_6": hs.numpy()[0, ::6]})
+        save("real_audio_face", **out)
 
     meta_path = os.path.join(HERE, "golden_meta.json")
     old = json.load(open(meta_path)) if os.path.exists(meta_path) else {"cases": {}}

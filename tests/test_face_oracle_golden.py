@@ -32,3 +32,26 @@ def test_linear_interpolation_endpoints():
     x = np.arange(499, dtype=np.float32)[None, :, None]
     y = FO.linear_interpolation(x, 300)[0, :, 0]
     assert y.shape == (300,) and abs(y[0] - 0.3316667) < 1e-4 and y[-1] <= 498 and np.all(np.diff(y) > 0)
+
+
+def test_face_generator_on_a_recording(golden):
+    """Real speech (tests/golden/real_audio_face.npz: the reference wrapper on its own demo recordings): french.wav, 9.6 s at
+    16 kHz as the host kaiser_best twin produces it (tests/golden/audio/french.wav.wav16.npy, a build-time file; skipped without it)."""
+    import hashlib
+    import os
+    import pytest
+    g = golden("real_audio_face")
+    side = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "audio", "french.wav.wav16.npy")
+    if not os.path.exists(side):
+        pytest.skip("tests/golden/audio/french.wav.wav16.npy is absent (__graft_entry__.build() writes it where /root/reference exists)")
+    wav = np.load(side)
+    if hashlib.sha256(wav.tobytes()).hexdigest() != str(g["french_wav16_sha256"]):
+        pytest.skip("the side file is not the golden's input")
+    N, frame, spk = (int(v) for v in g["french_n"])
+    sd = synth.face_state_dict(seed=7)
+    hs = FO.wav2vec2_forward(wav[None], sd, frame)
+    np.testing.assert_allclose(hs[0, ::6], g["french_hidden_6"], atol=5e-5, rtol=0)
+    ids = np.zeros((1, 4), np.float32)
+    np.testing.assert_allclose(FO.face_generator(wav[None], ids, sd, frame)[0], g["french_out_zero_id"], atol=1e-4, rtol=0)
+    ids[0, spk] = 1.0
+    np.testing.assert_allclose(FO.face_generator(wav[None], ids, sd, frame)[0], g["french_out_one_hot"], atol=1e-4, rtol=0)

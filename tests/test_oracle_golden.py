@@ -180,3 +180,28 @@ def test_torch_port_pixelcnn_greedy(golden, name):
     with torch.no_grad():
         codes = TP.pixelcnn_generate(torch.from_numpy(g["label"]), aud, sd, n_layers, g["codes"].shape[1])
     np.testing.assert_array_equal(codes.numpy(), g["codes"])
+
+
+# ---- real audio: the reference's own demo recordings (tests/golden/real_audio_body.npz) ---------------------
+@pytest.mark.parametrize("rec", ["style", "1st_page", "french"])
+def test_audio_encoder_on_recordings(golden, rec):
+    """MFCC rows of real speech reach 470 .. 660 (the synthetic rows ~80): the audio encoder restatement against the reference's
+    AudioEncoder on them."""
+    g = golden("real_audio_body")
+    rows = g[rec + "_rows"]
+    assert np.abs(rows).max() > 400
+    out = O.audio_encoder(np.ascontiguousarray(rows.T[None]), synth.audioencoder_state_dict(seed=7))
+    np.testing.assert_allclose(out[0].T, g[rec + "_aud_feat"], atol=TOL, rtol=0)
+
+
+@pytest.mark.slow
+def test_body_on_a_recording(golden):
+    """french.wav (H = 72) under two of the four speaker ids: the oracle's whole path against the reference's greedy harness and
+    decoders on real-speech rows — codes equal, poses within 1e-4."""
+    g = golden("real_audio_body")
+    rows, spk = g["french_rows"], int(g["french_pose_id"])
+    ids = np.asarray([0, spk], np.int64)
+    codes, poses, _ = O.body_pixel_infer(np.repeat(rows[None], 2, 0), ids, synth.audioencoder_state_dict(seed=7), synth.pixelcnn_state_dict(seed=7),
+                                         synth.vqvae_state_dict(seed=7, in_dim=39), synth.vqvae_state_dict(seed=7, in_dim=90, salt=1))
+    np.testing.assert_array_equal(codes, g["french_codes"][ids])
+    np.testing.assert_allclose(poses[1], g["french_poses"], atol=1e-4, rtol=0)
