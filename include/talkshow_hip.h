@@ -16,6 +16,17 @@
  *     and return; the caller synchronises (torch.cuda.synchronize() / hipStreamSynchronize).
  *   - weights are handed over ONCE as the reference's own state_dict (name, host pointer, shape); BatchNorm
  *     folding, mask-A zeroing, tap/segment packing and upload happen inside the library.
+ *
+ * Threads (the reference is single-threaded, default stream: SURVEY.md §8b)
+ *   - ONE HOST THREAD PER STREAM AT A TIME.  Handles (ts_ctx, ts_convnet, ts_vqvae, ts_pixelcnn, ts_face, ts_mfcc, ts_smplx) hold
+ *     read-only weights plus one scratch arena and one hipGraph cache PER STREAM; several host threads may call into the same
+ *     handles concurrently as long as each thread uses its own stream (the per-stream maps are mutex-guarded; a stream's arena and
+ *     graphs are only touched by the thread driving that stream).  Two threads on the same stream at the same time is a data race.
+ *   - create / destroy / ts_face_set_arith / ts_prof_enable of a handle must not run concurrently with calls on that handle.
+ *   - ts_pixelcnn_stream sessions belong to the thread that steps them.
+ *   - ts_last_error() is thread-local.  ts_stream_destroy(stream) drops that stream's arenas in every live handle: no call on the
+ *     stream may be in progress.
+ *   Exercised by tests/test_gpu_threads.py (three host threads, one stream each, bit-equal to the serial run).
  */
 #ifndef TALKSHOW_HIP_H
 #define TALKSHOW_HIP_H
@@ -122,6 +133,18 @@ int ts_pixelcnn_generate(ts_pixelcnn *pix, const int64_t *label_dev, const float
                          const float *uniforms_dev, uint64_t seed, int64_t clip_index0, int64_t *codes_dev,
                          float *logits_dev, const int64_t *pre_codes_dev, const float *pre_aud_dev, int H0,
                          void *stream);
+
+/* hipGraph policy of ts_pixelcnn_generate / ts_body_pixel_infer (no counterpart in the reference, which launches eagerly): a one-shot
+ * call (H0 == 0) replays graphs captured per (stream, B, H, mode).  A shape runs on small length-independent CHUNK graphs (8 code rows
+ * each) until it is hot — its third sighting among the last 16 one-shot calls on the stream — and then gets one whole-call graph; at
+ * most 24 unpinned graphs per stream are kept (8 whole-call + 16 chunk / streaming-step graphs), least recently used of its class out
+ * first, destroyed behind an event (no host-side wait).  A serving host
+ * that knows its pass shapes calls ts_pixelcnn_prepare once per (stream, shape): the whole-call graph is captured there (nothing
+ * runs), pinned (never evicted; at most 12 per stream) and the first real call is already one replay. */
+int ts_pixelcnn_prepare(ts_pixelcnn *pix, int B, int H, int mode, void *stream);
+/* hipGraphs captured + instantiated on `stream` since the handle was created, or -1 (a serving loop checks that this stands still
+ * once it is warm; bench.py asserts it over its timed regions). */
+long ts_pixelcnn_graph_captures(ts_pixelcnn *pix, void *stream);
 
 /* GatedPixelCNN(input_dim, dim, n_layers, n_classes, audio, bh_model=False) — the single-stack form (gated_pixelcnn_v2.py:37-42,
  * 80-85,147-150): vertical kernels one column wide, out_v = horiz_resid(gate(vert_stack(x_v) + class)) [+ x_v], logits from x_v; the

@@ -40,6 +40,8 @@
 // (ts_pixelcnn_stream_*) continues at the row where its previous step stopped, on a row cache that persists in its Work.
 #include <algorithm>
 #include <cstdlib>
+#include <deque>
+#include <set>
 #include <tuple>
 
 #include "host_common.h"
@@ -86,33 +88,87 @@ struct ts_pixelcnn {
         hipStream_t cap_stream = nullptr;
         // Captured graphs, least recently used out first: at most GRAPH_CAP per Work.  Keys: (B, H, H0, mode) = a whole one-shot call;
         // (B, Hc, -(1 + phase), mode) = Hc rows of a chunked one-shot call; (B, Hc, 1000 + phase, mode) = a streaming step.
+        // At most GRAPH_CAP unpinned graphs + PIN_CAP pinned ones per Work.
         typedef std::tuple<int, int, int, int> Key;
         struct Entry {
             hipGraphExec_t exec;
             uint64_t used;
         };
         static constexpr size_t GRAPH_CAP = 24;
+        static constexpr size_t PIN_CAP = 12;                 // shapes a host may pin with ts_pixelcnn_prepare (they are never evicted)
+        static constexpr size_t RECENT = 16;                  // window of one-shot calls a shape must recur in to count as hot
         std::map<Key, Entry> graphs;
         std::map<Key, std::pair<long, double>> graph_stats;   // skinny launches, flops
-        std::map<Key, int> seen;                              // one-shot shapes met so far (a shape gets its own whole-call graph the second time)
+        std::set<Key> pinned;
+        std::deque<Key> recent;                               // the last RECENT one-shot (H0 = 0) shapes that found no whole-call graph
+        // graphs taken out of the cache while a replay of them may still be queued on the stream: destroyed once the event recorded
+        // behind them has completed (no host-side wait on the serving stream)
+        struct Retired {
+            hipGraphExec_t exec;
+            hipEvent_t done;
+        };
+        std::vector<Retired> retired;
         uint64_t tick = 0;
+        long captures = 0;                                    // graphs captured + instantiated on this stream so far
+        // A one-shot shape gets its own whole-call graph (~36 H nodes: tens of milliseconds to capture and instantiate) only when it is
+        // HOT: pinned by the host, or met for the third time within the last RECENT one-shot calls on this stream.  A pass over a
+        // dataset of many distinct lengths (scripts/test_body.py:113-194), however often it is repeated, never qualifies and keeps running
+        // on the length-independent chunk graphs; a serving loop on one or a few shapes qualifies on its third call.
+        bool hot(const Key &k) {
+            if (pinned.count(k)) return true;
+            int n = 0;
+            for (const Key &r : recent) n += r == k;
+            recent.push_back(k);
+            if (recent.size() > RECENT) recent.pop_front();
+            return n >= 2;
+        }
+        void reap(bool wait) {
+            size_t keep = 0;
+            for (size_t i = 0; i < retired.size(); ++i) {
+                Retired &r = retired[i];
+                if (wait) (void)hipEventSynchronize(r.done);
+                if (wait || hipEventQuery(r.done) == hipSuccess) {
+                    (void)hipGraphExecDestroy(r.exec);
+                    (void)hipEventDestroy(r.done);
+                } else {
+                    retired[keep++] = r;
+                }
+            }
+            retired.resize(keep);
+        }
         void drop_graphs() {
+            reap(true);
             for (auto &kv : graphs) (void)hipGraphExecDestroy(kv.second.exec);
             graphs.clear();
-            graph_stats.clear();
+            graph_stats.clear();            // `pinned` stays: a pinned shape whose graph went with a buffer growth is re-captured by its next call
         }
-        // room for one more graph: the least recently used one goes (after the stream it may still be running on has drained)
-        int make_room(hipStream_t s) {
-            while (graphs.size() >= GRAPH_CAP) {
-                auto lru = graphs.begin();
-                for (auto it = graphs.begin(); it != graphs.end(); ++it)
-                    if (it->second.used < lru->second.used) lru = it;
-                TS_HIP(hipStreamSynchronize(s));
-                (void)hipGraphExecDestroy(lru->second.exec);
+        // Two classes share the cache: whole-call graphs of hot one-shot shapes (key field 2 = H0 in [0, 1000): at most WHOLE_CAP
+        // unpinned ones) and the length-independent chunk / streaming-step graphs (at most GRAPH_CAP - WHOLE_CAP) — a burst of hot
+        // shapes never pushes out the chunk graphs every other call falls back on.  Room for one more graph of `key`'s class: the least
+        // recently used unpinned graph of that class leaves the cache; it is destroyed behind an event on `s`.
+        static constexpr size_t WHOLE_CAP = 8;
+        static bool whole(const Key &k) { return std::get<2>(k) >= 0 && std::get<2>(k) < 1000; }
+        int make_room(hipStream_t s, const Key &key) {
+            reap(false);
+            const bool cls = whole(key);
+            const size_t cap = cls ? WHOLE_CAP : GRAPH_CAP - WHOLE_CAP;
+            for (;;) {
+                size_t n = 0;
+                auto lru = graphs.end();
+                for (auto it = graphs.begin(); it != graphs.end(); ++it) {
+                    if (whole(it->first) != cls || pinned.count(it->first)) continue;
+                    ++n;
+                    if (lru == graphs.end() || it->second.used < lru->second.used) lru = it;
+                }
+                if (n < cap) break;
+                Retired r{lru->second.exec, nullptr};
+                TS_HIP(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+                TS_HIP(hipEventRecord(r.done, s));
+                retired.push_back(r);
                 graph_stats.erase(lru->first);
                 graphs.erase(lru);
             }
-            if (seen.size() > 4096) seen.clear();
+            if (retired.size() > 2 * GRAPH_CAP) reap(true);   // a host that never lets the stream drain: bounded all the same
             return 0;
         }
         ~Work() {
@@ -845,6 +901,12 @@ int ts_pixelcnn_create(ts_ctx *ctx, const ts_tensor *sd_, int n, int V, int D, i
 }
 void ts_pixelcnn_destroy(ts_pixelcnn *p) { delete p; }
 
+long ts_pixelcnn_graph_captures(ts_pixelcnn *p, void *stream) {
+    if (!p) return -1;
+    ts_pixelcnn::Work *w = p->works.find((hipStream_t)stream);
+    return w ? w->captures : 0;
+}
+
 int ts_debug_pixelcnn_graphs(ts_pixelcnn *p, void *stream) {
     if (!p) return -1;
     ts_pixelcnn::Work *w = p->works.find((hipStream_t)stream);
@@ -903,7 +965,7 @@ int class_rows(ts_pixelcnn *p, ts_pixelcnn::Work *w, const int64_t *label, int B
 // staging buffer (every pointer inside a captured kernel is a Work buffer, so a graph is valid for any caller pointers);
 // the caller's arrays hold c.out_H rows per clip, of which this run covers rows c.out_row0 .. c.out_row0 + c.H - 1.
 int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const ts_pixelcnn::Work::Key &key,
-             const float *uniforms, int64_t *codes, hipStream_t s) {
+             const float *uniforms, int64_t *codes, hipStream_t s, bool capture_only = false) {
     ts_ctx *ctx = p->ctx;
     ts_pixelcnn::Work *w = c.w;
     const int out_H = c.out_H > 0 ? c.out_H : c.H;
@@ -923,15 +985,15 @@ int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const
     c.codes = static_cast<int64_t *>(w->codes_int.p);
     c.uniforms = c.mode == TS_SAMPLE_UNIFORMS ? w->unif_int.f() : nullptr;
     c.dyn = static_cast<const uint64_t *>(w->dyn.p);
-    if (c.mode == TS_SAMPLE_UNIFORMS)
+    if (c.mode == TS_SAMPLE_UNIFORMS && !capture_only)
         TS_HIP(hipMemcpy2DAsync(w->unif_int.p, (size_t)c.H * 2 * sizeof(float), uniforms + (size_t)c.out_row0 * 2,
                                 (size_t)out_H * 2 * sizeof(float), (size_t)c.H * 2 * sizeof(float), c.B, hipMemcpyDeviceToDevice, s));
     // the call's sampler words travel as the ARGUMENTS of a one-thread launch (copied when the launch is queued): no host buffer
     // has to stay intact behind the call, so any number of calls may be queued on the stream without a synchronisation
-    TS_HIP(launch_set_words3(static_cast<uint64_t *>(w->dyn.p), c.seed, (uint64_t)c.clip0, (uint64_t)c.pos_base, s));
+    if (!capture_only) TS_HIP(launch_set_words3(static_cast<uint64_t *>(w->dyn.p), c.seed, (uint64_t)c.clip0, (uint64_t)c.pos_base, s));
     auto it = w->graphs.find(key);
     if (it == w->graphs.end()) {
-        TS_TRY(w->make_room(s));
+        TS_TRY(w->make_room(s, key));
         if (!w->cap_stream) TS_HIP(hipStreamCreateWithFlags(&w->cap_stream, hipStreamNonBlocking));
         hipGraph_t g = nullptr;
         const long l0 = ctx->n_launch[FAM_SKINNY];
@@ -949,8 +1011,10 @@ int run_rows(ts_pixelcnn *p, RunCfg c, int r_begin, int r_end, bool graph, const
         const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (ei != hipSuccess) return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+        ++w->captures;
         it = w->graphs.emplace(key, ts_pixelcnn::Work::Entry{ex, 0}).first;
     }
+    if (capture_only) return 0;
     it->second.used = ++w->tick;
     TS_HIP(hipGraphLaunch(it->second.exec, s));
     TS_HIP(hipMemcpy2DAsync(codes + (size_t)c.out_row0 * 2, (size_t)out_H * 2 * sizeof(int64_t), w->codes_int.p,
@@ -1036,11 +1100,32 @@ int ts_pixelcnn_generate(ts_pixelcnn *p, const int64_t *label, const float *aud,
         TS_HIP(launch_i64_to_i32(tf, w->tok32.i(), (long)B * Htot * 2, s));
     }
     const ts_pixelcnn::Work::Key key = std::make_tuple(B, H, H0, mode);
-    // A shape met for the first time runs as chunk graphs (two or three small captures that serve every clip length); the second
-    // time it gets its own whole-call graph (one replay per call: the serving loops, bench.py).  The cache is bounded either way.
-    if (graph && H0 == 0 && !w->graphs.count(key) && w->seen[key]++ == 0 && H > CHUNK_ROWS)
+    // A shape without a whole-call graph runs as chunk graphs (two or three small captures that serve every clip length) until it is
+    // hot (Work::hot: pinned by ts_pixelcnn_prepare, or its third sighting among the last 16 one-shot calls of this stream); then it gets
+    // its own whole-call graph (one replay per call: the serving loops, bench.py).  The cache is bounded either way.
+    if (graph && H0 == 0 && H > CHUNK_ROWS && !w->graphs.count(key) && !w->hot(key))
         return run_chunked(p, w, B, H, mode, uniforms, seed, clip0, codes, s);
     return run_rows(p, c, 0, Htot, graph, key, uniforms, codes, s);
+}
+
+// Captures (without running anything) the whole-call graph of a one-shot shape on `stream` and pins it: the first real call of that
+// shape is already a single replay, and the graph is never evicted.  Serving hosts call this for their pass shapes at start-up
+// (bench.py's warm()); nothing in the reference corresponds (it has no graphs).
+int ts_pixelcnn_prepare(ts_pixelcnn *p, int B, int H, int mode, void *stream) {
+    if (!p) return fail("ts_pixelcnn_prepare: null argument");
+    if (B < 1 || H < 1) return fail("ts_pixelcnn_prepare: bad shape");
+    if (mode != TS_SAMPLE_GREEDY && mode != TS_SAMPLE_UNIFORMS && mode != TS_SAMPLE_PHILOX) return fail("ts_pixelcnn_prepare: bad mode");
+    TS_HIP(hipSetDevice(p->ctx->device));
+    if (!p->use_graph) return 0;                                   // TS_NO_GRAPH: eager launches, nothing to prepare
+    hipStream_t s = (hipStream_t)stream;
+    ts_pixelcnn::Work *w = &p->work(s);
+    TS_TRY(ensure_work(p, w, B, H));
+    const ts_pixelcnn::Work::Key key = std::make_tuple(B, H, 0, mode);
+    if (!w->pinned.count(key) && w->pinned.size() >= ts_pixelcnn::Work::PIN_CAP) return fail("ts_pixelcnn_prepare: too many pinned shapes on this stream");
+    RunCfg c = one_shot_cfg(B, H, 0, mode, nullptr, 0, 0, nullptr, nullptr, w);
+    TS_TRY(run_rows(p, c, 0, H, true, key, nullptr, nullptr, s, /*capture_only=*/true));
+    w->pinned.insert(key);
+    return 0;
 }
 
 // ---- streaming generation (reference: the pre_latents / pre_audio prefix of gated_pixelcnn_v2.py:158-165

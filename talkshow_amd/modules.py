@@ -10,6 +10,7 @@ Shape conventions of the methods follow the reference (channels-first tensors in
 that `nets/` reads like the reference wrappers; the transposes to the library's NLC layout happen here, on device.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -390,6 +391,18 @@ class GatedPixelCNN(NativeModule):
             _lib.stream_ptr()))
         return codes, logits
 
+    def prepare(self, batch_size, rows, mode=_lib.TS_SAMPLE_GREEDY):
+        """Serving aid (`ts_pixelcnn_prepare`): capture and pin the whole-call hipGraph of a (batch_size, rows, mode) decode on the current
+        stream now, so that the first real call of that shape is already one replay.  Without it a shape runs on chunk graphs until its
+        third sighting among the stream's last 16 calls.  No-op for the untuned bh_model=False form."""
+        if self.bh_model:
+            _lib.check(_lib.load().ts_pixelcnn_prepare(self.handle(), int(batch_size), int(rows), int(mode), _lib.stream_ptr()))
+        return self
+
+    def graph_captures(self):
+        """hipGraphs captured so far on the current stream (a serving loop checks that this stands still once it is warm)."""
+        return int(_lib.load().ts_pixelcnn_graph_captures(self.handle(), _lib.stream_ptr())) if self.bh_model else 0
+
     def open_stream(self, label, batch_size, max_chunk_rows):
         """A generation session with a persistent row cache (`ts_pixelcnn_stream_*`): `.step(aud_rows)` continues the
         clip(s) where the previous step stopped, at a cost independent of the history length."""
@@ -405,9 +418,15 @@ class GatedPixelCNN(NativeModule):
         truncated to its first column."""
         if aud is None:
             return None
-        if aud.shape[-1] > 1 and not bool((aud == aud[..., :1]).all()):
-            raise NotImplementedError("GatedPixelCNN: the audio map's columns differ; one audio row per code row is supported "
-                                      "(the reference's caller repeats a row over the columns, smplx_body_pixel.py:274)")
+        # an expanded view (stride 0 over the columns: `unsqueeze(-1).expand`) or a single column cannot differ: no device work.  A
+        # materialised map (`.repeat(1, 1, 1, 2)`, the reference caller's form) costs one device compare + a host read per call on
+        # this reference-call-shape path (`generate_batch`, the serving entry, takes rows and never comes here); a host that has
+        # validated its maps switches it off with TS_AUDIO_MAP_CHECK=0.  NaNs are reported as NaNs, not as differing columns.
+        if aud.shape[-1] > 1 and aud.stride(-1) != 0 and os.environ.get("TS_AUDIO_MAP_CHECK", "1") != "0":
+            same = (aud == aud[..., :1]) | (aud != aud)
+            if not bool(same.all()):
+                raise NotImplementedError("GatedPixelCNN: the audio map's columns differ; one audio row per code row is supported "
+                                          "(the reference's caller repeats a row over the columns, smplx_body_pixel.py:274)")
         return aud[..., 0].transpose(1, 2)
 
     # --- reference call shapes ---

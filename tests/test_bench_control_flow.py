@@ -168,3 +168,73 @@ def test_collectives_can_be_forced_at_world_one(tmp_path):
     assert line["rccl"]["ranks_seen"] == 1 and line["rccl"]["gathered_shape"] == [12, 3, 2] and line["n_gpus"] == 1
     what = [json.loads(l)["what"] for l in open(tmp_path / "log.jsonl")]
     assert what.count("gather") == 2
+
+
+def _repeat_worker(rank, world, port, tmp):
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    job = StubJob(world, rank, os.path.join(tmp, f"log{rank}.jsonl"))
+    job.regions = []
+    job.region_begin = lambda: job.regions.append("begin")
+    job.region_end = lambda: job.regions.append("end")
+    # the second of the three regions is slow on every rank: the median must not be it, nor the fastest
+    slow = iter([1.0, 1.0, 4.0, 2.0])                                  # warm-up run, then regions 0, 1, 2
+    plain = job.run_steps
+    job.run_steps = lambda k: (time.sleep(0.02 * next(slow)), plain(k))[1]
+    dt, _, info = bench.run_contract(job, dist, world, rank, 3, 1, repeats=3)
+    lines = []
+    bench.finish(job, dist, world, rank, 3, 1, dt, info, emit=lines.append)
+    with open(os.path.join(tmp, f"rep{rank}.json"), "w") as f:
+        json.dump({"lines": lines, "dt": dt, "runs": job.contract_runs, "regions": job.regions}, f)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_repeated_timed_regions_report_the_median(tmp_path, world):
+    """`--repeats 3` = three bracketed regions of exactly `steps` steps in the same warm state; `value` is the
+    median region's, every region's time rides along in `runs_ms`, each region has its own barriers / exchange / MAX over ranks."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_repeat_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [json.load(open(tmp_path / f"rep{r}.json")) for r in range(world)]
+    line = json.loads(outs[0]["lines"][0])
+    runs = outs[0]["runs"]["runs_ms"]
+    assert len(runs) == 3 and line["runs_ms"] == runs and outs[0]["regions"] == ["begin", "end"] * 3
+    assert runs[1] > runs[2] > runs[0]                                   # 4x, 2x, 1x of the extra sleep
+    assert outs[0]["runs"]["median_index"] == 2 and abs(outs[0]["dt"] * 1e3 - runs[2]) < 1e-9
+    assert abs(line["ms_per_step"] - runs[2] / 3) < 1e-9 and abs(line["value"] - world * 3 * 4 * 300 / outs[0]["dt"]) < 1e-6 * line["value"]
+    assert 0 <= line["host_cpu_s"] and line["runs_spread"] > 0.2
+    assert all(o["runs"]["runs_ms"] == runs and o["dt"] == outs[0]["dt"] for o in outs) if world > 1 else True   # MAX over ranks per region
+    for r in range(world):
+        what = [json.loads(l)["what"] for l in open(tmp_path / f"log{r}.jsonl")]
+        assert what.count("run_steps 3") == 3 and what.count("gather") == (4 if world > 1 else 0)
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher(tmp_path):
+    """`python bench.py --gpus N` with WORLD_SIZE unset used to die on an assert.  `needs_spawn` / `spawn_ranks`
+    start the N ranks through torch.distributed.run (the driver's launcher) — here a probe script on gloo at world 2 stands in for
+    bench.py's GPU body: both ranks come up with the launcher's environment, rendezvous on 127.0.0.1 and all-reduce."""
+    import sys
+    import bench
+    assert bench.needs_spawn({}, 8) and bench.needs_spawn({"PATH": "x"}, 2)
+    assert not bench.needs_spawn({}, 1) and not bench.needs_spawn({"WORLD_SIZE": "8", "RANK": "3"}, 8)
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import json, os, sys, torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(dist.get_rank() + 1)]); dist.all_reduce(t)\n"
+        "json.dump({'rank': dist.get_rank(), 'world': dist.get_world_size(), 'sum': t.item(), 'args': sys.argv[1:],\n"
+        "           'spawned': os.environ.get('TS_BENCH_SPAWNED'), 'addr': os.environ['MASTER_ADDR']},\n"
+        "          open(os.path.join(sys.argv[1], f'probe{dist.get_rank()}.json'), 'w'))\n"
+        "dist.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    rc = bench.spawn_ranks(2, str(probe), [str(tmp_path), "--steps", "20"], env=env, timeout=240)
+    assert rc == 0
+    got = [json.load(open(tmp_path / f"probe{r}.json")) for r in range(2)]
+    assert [g["rank"] for g in got] == [0, 1] and all(g["world"] == 2 and g["sum"] == 3.0 and g["spawned"] == "1" for g in got)
+    assert all(g["addr"] == "127.0.0.1" and g["args"] == [str(tmp_path), "--steps", "20"] for g in got)
+    # and a failing rank's exit code comes back
+    bad = tmp_path / "bad.py"
+    bad.write_text("import sys; sys.exit(3)\n")
+    assert bench.spawn_ranks(2, str(bad), [], env=env, timeout=240) != 0

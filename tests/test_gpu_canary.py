@@ -1,0 +1,333 @@
+"""Memory-safety witnesses for the hand-indexed kernels.
+
+GPU AddressSanitizer needs xnack+ code objects and `HSA_XNACK=1`; this GPU pool refuses both (the `gpurun` client rejects such
+commands), so the evidence is the canary / poison harness below, which stays in the suite:
+
+* every OUTPUT of an entry point lives inside a larger buffer whose red zones (4 KiB on both sides) AND body are pre-filled
+  with a sentinel bit pattern; after the call the red zones must still hold it bit for bit — a stray store outside
+  [base, base + size) shows up there — and every body element the call is documented to write must have lost it;
+* every INPUT lives between red zones of NaN (float) / an impossible index (int64): a load outside the input whose value reaches
+  an output turns that output into NaN / a launch failure, and the outputs must equal, bit for bit, the same call on plain
+  tightly allocated tensors (the kernels are deterministic);
+* shapes are the ragged ones: B in {1, 33, 255}, T in {31, 78, 301}, odd sample counts, output columns that do not start at 0,
+  channel counts that are not multiples of a tile.
+
+(Loads that stay inside the padded scratch the library owns — e.g. `skinny_wide.hip`'s clamped rows: "computed, never stored" —
+are by construction inside an allocation; what this harness pins is that nothing caller-visible is read or written out of bounds.)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from talkshow_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PAD = 1024                                  # elements of red zone on each side (4 KiB of fp32, 8 KiB of int64): keeps the base 256-byte aligned
+F_SENT = np.uint32(0x7FC0BEEF)              # a quiet NaN with a payload no kernel produces
+I_SENT = np.int64(0x7EADBEEF7EADBEEF)       # an index no table holds
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from talkshow_amd import _lib
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return _lib, _lib.load(), _lib.context(0)
+
+
+class Guarded:
+    """A tensor of `shape` between two red zones.  kind 'out': zones and body hold the sentinel; kind 'in': zones hold the
+    sentinel (NaN / impossible index), the body holds `data`."""
+
+    def __init__(self, shape, dtype, data=None):
+        self.shape, self.dtype = tuple(int(s) for s in shape), dtype
+        self.n = int(np.prod(self.shape)) if self.shape else 1
+        ity = torch.int32 if dtype == torch.float32 else torch.int64
+        sent = int(F_SENT) if dtype == torch.float32 else int(I_SENT)
+        if dtype == torch.float64:
+            sent = int(I_SENT)
+        self.sent = sent
+        self.raw = torch.full((2 * PAD + self.n,), sent, dtype=ity, device="cuda")
+        self.body = self.raw[PAD:PAD + self.n].view(dtype).view(self.shape)
+        if data is not None:
+            self.body.copy_(torch.as_tensor(np.ascontiguousarray(data)).to(dtype).reshape(self.shape))
+
+    def ptr(self):
+        return C.c_void_p(self.body.data_ptr())
+
+    def zones_intact(self):
+        return bool((self.raw[:PAD] == self.sent).all()) and bool((self.raw[PAD + self.n:] == self.sent).all())
+
+    def bits(self):
+        return self.raw[PAD:PAD + self.n].cpu().numpy().copy()
+
+
+def plain_out(shape, dtype):
+    """A tightly allocated output pre-filled with the same sentinel, so 'never written' compares equal on both sides."""
+    g = Guarded(shape, dtype)
+    t = g.raw[PAD:PAD + g.n].clone()
+    return t.view(dtype).view(g.shape), t
+
+
+def run_both(call, ins, outs, written=None):
+    """call(ptrs: dict name -> c_void_p) enqueues the entry point.  ins: name -> (np array, torch dtype); outs: name -> (shape, dtype).
+    Runs it on plain tensors and on guarded ones; asserts red zones intact, bodies bit-equal, and — for the outputs named in
+    `written` (default: all) — that no element kept the sentinel."""
+    from talkshow_amd import _lib
+    plain_in = {k: torch.as_tensor(np.ascontiguousarray(a)).to(dt).cuda() for k, (a, dt) in ins.items()}
+    plain = {k: plain_out(s, dt) for k, (s, dt) in outs.items()}
+    ptrs = {k: C.c_void_p(t.data_ptr()) for k, t in plain_in.items()}
+    ptrs.update({k: C.c_void_p(v[0].data_ptr()) for k, v in plain.items()})
+    call(ptrs)
+    torch.cuda.synchronize()
+    g_in = {k: Guarded(a.shape, dt, a) for k, (a, dt) in ins.items()}
+    g_out = {k: Guarded(s, dt) for k, (s, dt) in outs.items()}
+    ptrs = {k: g.ptr() for k, g in g_in.items()}
+    ptrs.update({k: g.ptr() for k, g in g_out.items()})
+    call(ptrs)
+    torch.cuda.synchronize()
+    for k, g in g_in.items():
+        assert g.zones_intact(), f"input {k}: a red zone was written"
+        assert np.array_equal(g.bits(), Guarded(g.shape, g.dtype, ins[k][0]).bits()), f"input {k} was modified"
+    res = {}
+    for k, g in g_out.items():
+        assert g.zones_intact(), f"output {k}: a store landed outside [base, base + {g.n} elements)"
+        a, b = g.bits(), plain[k][1].cpu().numpy()
+        assert np.array_equal(a, b), f"output {k}: the call between NaN red zones differs from the plain call in {int((a != b).sum())} elements"
+        if written is None or k in written:
+            left = int((a == g.sent).sum())
+            assert left == 0, f"output {k}: {left} of {g.n} elements were never written"
+        res[k] = g.body
+    return res
+
+
+F32, I64, F64 = torch.float32, torch.int64, torch.float64
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,K,stride,tr,act", [
+    (1, 31, 64, 64, 3, 1, 0, 1), (3, 75, 39, 200, 3, 1, 0, 2), (2, 78, 129, 65, 1, 1, 0, 0), (33, 31, 64, 128, 4, 2, 0, 1),
+    (5, 301, 100, 36, 4, 2, 0, 0), (2, 19, 130, 90, 4, 2, 1, 0), (7, 75, 64, 39, 4, 2, 1, 2), (1, 1, 8, 8, 3, 1, 0, 0)])
+def test_op_conv1d_canary(hip, B, L, Cin, Cout, K, stride, tr, act):
+    _lib, lib, ctx = hip
+    rng = np.random.default_rng(B * 1000 + L)
+    x = rng.standard_normal((B, L, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K) if tr else (Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    pad = 1 if K in (3, 4) else 0
+    Lout = 2 * L if tr else (L + 2 * pad - K) // stride + 1
+    run_both(lambda p: _lib.check(lib.ts_op_conv1d(ctx, p["x"], B, L, Cin, _lib.fptr(w), _lib.fptr(b), Cout, K, stride, pad, tr, act, p["out"], None)),
+             {"x": (x, F32)}, {"out": ((B, Lout, Cout), F32)})
+
+
+@pytest.mark.parametrize("M,ncode,dim", [(1, 2048, 64), (33, 2048, 64), (2399, 2048, 64), (75, 128, 64), (300, 1000, 64)])
+def test_op_vq_argmin_canary(hip, M, ncode, dim):
+    _lib, lib, ctx = hip
+    rng = np.random.default_rng(M)
+    x, cb = rng.standard_normal((M, dim)).astype(np.float32), rng.standard_normal((ncode, dim)).astype(np.float32)
+    r = run_both(lambda p: _lib.check(lib.ts_op_vq_argmin(ctx, p["x"], M, p["cb"], ncode, dim, p["idx"], None)),
+                 {"x": (x, F32), "cb": (cb, F32)}, {"idx": ((M,), I64)})
+    d = (x.astype(np.float64) ** 2).sum(1)[:, None] + (cb.astype(np.float64) ** 2).sum(1)[None] - 2.0 * x.astype(np.float64) @ cb.astype(np.float64).T
+    got = r["idx"].cpu().numpy()
+    assert ((got >= 0) & (got < ncode)).all()
+    assert (np.abs(d[np.arange(M), got] - d.min(1)) < 1e-3).all()
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(1, 256, 512, 0), (33, 512, 2048, 1), (255, 256, 256, 0), (7, 768, 100, 0), (64, 136, 257, 1)])
+def test_op_linear_and_sample_canary(hip, M, K, N, relu):
+    _lib, lib, ctx = hip
+    rng = np.random.default_rng(M + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w, b = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    r = run_both(lambda p: _lib.check(lib.ts_op_linear(ctx, p["x"], M, K, _lib.fptr(w), _lib.fptr(b), N, relu, p["out"], None)),
+                 {"x": (x, F32)}, {"out": ((M, N), F32)})
+    logits = r["out"].cpu().numpy()
+    u = rng.random(M).astype(np.float32)
+    run_both(lambda p: _lib.check(lib.ts_op_sample(ctx, p["lg"], M, N, _lib.TS_SAMPLE_GREEDY, None, p["idx"], None)),
+             {"lg": (logits, F32)}, {"idx": ((M,), I64)})
+    run_both(lambda p: _lib.check(lib.ts_op_sample(ctx, p["lg"], M, N, _lib.TS_SAMPLE_UNIFORMS, p["u"], p["idx"], None)),
+             {"lg": (logits, F32), "u": (u, F32)}, {"idx": ((M,), I64)})
+    run_both(lambda p: _lib.check(lib.ts_op_sample_philox(ctx, p["lg"], M, N, 77, 5, 3, p["idx"], None)),
+             {"lg": (logits, F32)}, {"idx": ((M,), I64)})
+
+
+@pytest.fixture(scope="module")
+def full_nets():
+    import bench
+    w, _ = bench.build_models(0)
+    return w
+
+
+@pytest.mark.parametrize("B,T", [(1, 31), (33, 78), (255, 301), (2, 4), (32, 300), (256, 300), (257, 75)])
+def test_body_pixel_infer_canary(hip, full_nets, B, T):
+    """The whole body call at full network size: split-K kernels (B <= 159), the wide kernel (B >= 160, ragged last row tile at 255 /
+    257), clip lengths that are not multiples of 4."""
+    _lib, lib, ctx = hip
+    w = full_nets
+    H = T // 4
+    mf, ids = synth.mfcc_features(B + T, B, T), synth.speaker_ids(B)
+    r = run_both(lambda p: _lib.check(lib.ts_body_pixel_infer(
+        w.audioencoder.handle(), w.generator.handle(), w.g_body.handle(), w.g_hand.handle(), p["mfcc"], p["ids"], B, T,
+        _lib.TS_SAMPLE_GREEDY, None, 0, 0, p["codes"], p["poses"], _lib.stream_ptr())),
+        {"mfcc": (mf, F32), "ids": (ids, I64)}, {"codes": ((B, H, 2), I64), "poses": ((B, 4 * H, 129), F32)})
+    codes = r["codes"].cpu().numpy()
+    assert ((codes >= 0) & (codes < 2048)).all() and torch.isfinite(r["poses"]).all()
+    # stochastic decode with caller uniforms: one more input to poison
+    u = np.random.default_rng(B).random((B, H, 2)).astype(np.float32)
+    run_both(lambda p: _lib.check(lib.ts_body_pixel_infer(
+        w.audioencoder.handle(), w.generator.handle(), w.g_body.handle(), w.g_hand.handle(), p["mfcc"], p["ids"], B, T,
+        _lib.TS_SAMPLE_UNIFORMS, p["u"], 0, 0, p["codes"], p["poses"], _lib.stream_ptr())),
+        {"mfcc": (mf, F32), "ids": (ids, I64), "u": (u, F32)}, {"codes": ((B, H, 2), I64), "poses": ((B, 4 * H, 129), F32)})
+
+
+@pytest.mark.parametrize("B,T", [(1, 31), (33, 78), (255, 301), (32, 300)])
+def test_body_vq_and_decoders_canary(hip, full_nets, B, T):
+    """VQ encode / decode entry points: encode-only and encode + decode forms of the pair call, single-network encode with z and
+    quantized outputs, decode into columns [39, 129) of a 129-wide row (out_col0 != 0: the other columns keep the sentinel)."""
+    _lib, lib, ctx = hip
+    w = full_nets
+    H = T // 4
+    poses = synth.gt_poses(B + T, B, T)
+    s = _lib.stream_ptr()
+    r = run_both(lambda p: _lib.check(lib.ts_body_vq_infer(w.g_body.handle(), w.g_hand.handle(), p["poses"], B, T, p["codes"], p["recon"], s)),
+                 {"poses": (poses, F32)}, {"codes": ((B, H, 2), I64), "recon": ((B, 4 * H, 129), F32)})
+    r2 = run_both(lambda p: _lib.check(lib.ts_body_vq_infer(w.g_body.handle(), w.g_hand.handle(), p["poses"], B, T, p["codes"], None, s)),
+                  {"poses": (poses, F32)}, {"codes": ((B, H, 2), I64)})
+    assert torch.equal(r["codes"], r2["codes"])
+    hand = np.ascontiguousarray(poses[..., 39:])
+    e = run_both(lambda p: _lib.check(lib.ts_vqvae_encode(w.g_hand.handle(), p["x"], B, T, p["z"], p["lat"], p["q"], s)),
+                 {"x": (hand, F32)}, {"z": ((B, H, 64), F32), "lat": ((B, H), I64), "q": ((B, H, 64), F32)})
+    lat = e["lat"].cpu().numpy()
+    assert np.array_equal(lat, r["codes"].cpu().numpy()[..., 1])
+    d = run_both(lambda p: _lib.check(lib.ts_vqvae_decode(w.g_hand.handle(), p["lat"], B, H, p["out"], 129, 39, s)),
+                 {"lat": (lat, I64)}, {"out": ((B, 4 * H, 129), F32)}, written=())
+    bits = d["out"].view(torch.int32)
+    assert bool((bits[..., :39] == int(F_SENT)).all()), "decode with out_col0 = 39 wrote into columns [0, 39)"
+    assert not bool((bits[..., 39:] == int(F_SENT)).any())
+    assert torch.equal(d["out"][..., 39:], r["recon"][..., 39:])
+    z = e["z"].cpu().numpy()
+    run_both(lambda p: _lib.check(lib.ts_vqvae_decode_z(w.g_hand.handle(), p["z"], B, H, p["out"], 90, 0, s)),
+             {"z": (z, F32)}, {"out": ((B, 4 * H, 90), F32)})
+    run_both(lambda p: _lib.check(lib.ts_vqvae_decode_pair(w.g_body.handle(), w.g_hand.handle(), p["lb"], p["lh"], B, H, p["out"], s)),
+             {"lb": (np.ascontiguousarray(r["codes"].cpu().numpy()[..., 0]), I64), "lh": (lat, I64)}, {"out": ((B, 4 * H, 129), F32)})
+    run_both(lambda p: _lib.check(lib.ts_audioenc_forward(w.audioencoder.handle(), p["mfcc"], B, T, p["feat"], s)),
+             {"mfcc": (synth.mfcc_features(B, B, T), F32)}, {"feat": ((B, H, 256), F32)})
+
+
+@pytest.mark.parametrize("B,H,H0", [(1, 1, 0), (3, 7, 0), (33, 5, 3), (255, 3, 0)])
+def test_pixelcnn_generate_and_stream_canary(hip, full_nets, B, H, H0):
+    """The chain alone: logits output, continuity prefix, injected uniforms; and the streaming session in two chunks."""
+    _lib, lib, ctx = hip
+    px = full_nets.generator
+    s = _lib.stream_ptr()
+    rng = np.random.default_rng(B * 7 + H)
+    aud = rng.standard_normal((B, H, 256)).astype(np.float32)
+    label = synth.speaker_ids(B)
+    pre_c = rng.integers(0, 2048, (B, H0, 2)).astype(np.int64)
+    pre_a = rng.standard_normal((B, H0, 256)).astype(np.float32)
+    ins = {"label": (label, I64), "aud": (aud, F32)}
+    if H0:
+        ins.update({"pc": (pre_c, I64), "pa": (pre_a, F32)})
+    run_both(lambda p: _lib.check(lib.ts_pixelcnn_generate(px.handle(), p["label"], p["aud"], B, H, _lib.TS_SAMPLE_GREEDY, None, 0, 0,
+                                                           p["codes"], p["logits"], p.get("pc"), p.get("pa"), H0, s)),
+             ins, {"codes": ((B, H, 2), I64), "logits": ((B, H, 2, 2048), F32)})
+    u = rng.random((B, H, 2)).astype(np.float32)
+    run_both(lambda p: _lib.check(lib.ts_pixelcnn_generate(px.handle(), p["label"], p["aud"], B, H, _lib.TS_SAMPLE_UNIFORMS, p["u"], 0, 0,
+                                                           p["codes"], None, p.get("pc"), p.get("pa"), H0, s)),
+             dict(ins, u=(u, F32)), {"codes": ((B, H, 2), I64)})
+    if H >= 2 and not H0:
+        h1 = H // 2
+
+        def stream_call(p):
+            st = C.c_void_p()
+            _lib.check(lib.ts_pixelcnn_stream_open(px.handle(), p["label"], B, H, C.byref(st)))
+            _lib.check(lib.ts_pixelcnn_stream_step(st, p["a0"], h1, _lib.TS_SAMPLE_GREEDY, None, 0, 0, p["c0"], s))
+            _lib.check(lib.ts_pixelcnn_stream_step(st, p["a1"], H - h1, _lib.TS_SAMPLE_GREEDY, None, 0, 0, p["c1"], s))
+            torch.cuda.synchronize()
+            lib.ts_pixelcnn_stream_close(st)
+        run_both(stream_call, {"label": (label, I64), "a0": (np.ascontiguousarray(aud[:, :h1]), F32), "a1": (np.ascontiguousarray(aud[:, h1:]), F32)},
+                 {"c0": ((B, h1, 2), I64), "c1": ((B, H - h1, 2), I64)})
+
+
+@pytest.mark.parametrize("B,N,frames", [(1, 16001, 30), (3, 47999, 89), (2, 160000, 300), (5, 32033, 60), (1, 400, 1)])
+def test_face_generate_canary(hip, B, N, frames):
+    """Odd sample counts (conv frame counts 49 .. 499 that are ragged against every tile), with and without the hidden-state output."""
+    import bench
+    _lib, lib, ctx = hip
+    m = test_face_generate_canary.m = getattr(test_face_generate_canary, "m", None) or bench.build_face(0)
+    wav = synth.wav16(N, B, N)
+    ids = np.eye(4, dtype=np.float32)[np.arange(B) % 4]
+    s = _lib.stream_ptr()
+    r = run_both(lambda p: _lib.check(lib.ts_face_generate(m.handle(), p["wav"], B, N, frames, p["ids"], p["out"], p["hid"], s)),
+                 {"wav": (wav, F32), "ids": (ids, F32)}, {"out": ((B, frames, 103), F32), "hid": ((B, frames, 768), F32)})
+    assert torch.isfinite(r["out"]).all() and torch.isfinite(r["hid"]).all()
+    run_both(lambda p: _lib.check(lib.ts_face_generate(m.handle(), p["wav"], B, N, frames, p["ids"], p["out"], None, s)),
+             {"wav": (wav, F32), "ids": (ids, F32)}, {"out": ((B, frames, 103), F32)})
+
+
+@pytest.mark.parametrize("sr_in,N,B", [(16000, 160000, 2), (44100, 100001, 1), (24000, 230700, 3), (22000, 1100, 1), (16000, 801, 1)])
+def test_frontend_canary(hip, sr_in, N, B):
+    """Resamplers and MFCC at odd lengths, down to clips barely longer than half an FFT window (shorter ones are refused: reflect
+    padding is undefined there, as for torch.stft under torchaudio's MFCC)."""
+    _lib, lib, ctx = hip
+    wav = synth.wav16(N + B, B, N)
+    s = _lib.stream_ptr()
+    h = C.c_void_p()
+    _lib.check(lib.ts_mfcc_create(ctx, sr_in, 22000, 30, C.byref(h)))
+    try:
+        T, N2 = lib.ts_mfcc_num_frames(h, N), lib.ts_mfcc_resampled_len(h, N)
+        assert T >= 1 and N2 >= 1
+        run_both(lambda p: _lib.check(lib.ts_mfcc_forward(h, p["wav"], B, N, p["feat"], s)), {"wav": (wav, F32)}, {"feat": ((B, T, 64), F32)})
+        run_both(lambda p: _lib.check(lib.ts_mfcc_resample(h, p["wav"], B, N, p["out"], s)), {"wav": (wav, F32)}, {"out": ((B, N2), F32)})
+    finally:
+        torch.cuda.synchronize()
+        lib.ts_mfcc_destroy(h)
+    if N < 1200:
+        hh = C.c_void_p()
+        _lib.check(lib.ts_mfcc_create(ctx, 22000, 22000, 30, C.byref(hh)))
+        feat = torch.empty((1, 2, 64), device="cuda")
+        assert lib.ts_mfcc_forward(hh, _lib.dptr(torch.zeros(1, 733, device="cuda")), 1, 733, _lib.dptr(feat), s) != 0
+        assert b"shorter than half an FFT window" in lib.ts_last_error()
+        lib.ts_mfcc_destroy(hh)
+    if sr_in != 16000:
+        N3 = lib.ts_resample_kaiser_len(N, sr_in, 16000)
+        run_both(lambda p: _lib.check(lib.ts_resample_kaiser(ctx, p["wav"], B, N, sr_in, 16000, p["out"], s)), {"wav": (wav, F32)}, {"out": ((B, N3), F32)})
+
+
+@pytest.mark.parametrize("B,Tb,Tf", [(1, 300, 300), (3, 75, 80), (33, 301, 288), (2, 1, 5)])
+def test_assemble_and_eval_canary(hip, B, Tb, Tf):
+    _lib, lib, ctx = hip
+    from talkshow_amd.pose_index import lower_pose_block
+    rng = np.random.default_rng(B + Tb)
+    body, face = rng.standard_normal((B, Tb, 129)).astype(np.float32), rng.standard_normal((B, Tf, 103)).astype(np.float32)
+    lp = np.ascontiguousarray(np.asarray(lower_pose_block(False), np.float32).reshape(-1))
+    run_both(lambda p: _lib.check(lib.ts_assemble_full(ctx, p["body"], Tb, p["face"], Tf, B, _lib.fptr(lp), p["out"], None)),
+             {"body": (body, F32), "face": (face, F32)}, {"out": ((B, Tf, 265), F32)})
+    # evaluation reductions: device doubles out
+    n, D = 7 * B + Tb, 64
+    feat = rng.standard_normal((n, D)).astype(np.float32)
+    run_both(lambda p: _lib.check(lib.ts_eval_feat_stats(ctx, p["f"], n, D, p["st"], None)), {"f": (feat, F32)}, {"st": ((D + D * D,), F64)})
+    a, b = rng.standard_normal(n * 3 + 1).astype(np.float32), rng.standard_normal(n * 3 + 1).astype(np.float32)
+    run_both(lambda p: _lib.check(lib.ts_eval_l1_total(ctx, p["a"], p["b"], n * 3 + 1, p["o"], None)), {"a": (a, F32), "b": (b, F32)}, {"o": ((1,), F64)})
+    T_, J_ = Tf + 1, 55
+    gt, pr = rng.standard_normal((T_, J_, 3)).astype(np.float32), rng.standard_normal((B + 1, T_, J_, 3)).astype(np.float32)
+    run_both(lambda p: _lib.check(lib.ts_eval_body_loss(ctx, p["gt"], p["pr"], B + 1, T_, J_, 22, T_, p["o"], None)),
+             {"gt": (gt, F32), "pr": (pr, F32)}, {"o": ((3,), F64)})
+    kps = rng.standard_normal((B + 1, Tb * 3 + 1)).astype(np.float32)
+    run_both(lambda p: _lib.check(lib.ts_eval_diversity(ctx, p["k"], B + 1, Tb * 3 + 1, p["o"], None)), {"k": (kps, F32)}, {"o": ((1,), F64)})
+
+
+@pytest.mark.parametrize("N", [1, 33, 301])
+def test_smplx_forward_canary(hip, N):
+    from oracle import smplx_oracle as SO
+    from talkshow_amd import smplx_lbs
+    _lib, lib, ctx = hip
+    model = SO.synthetic_model(seed=3)
+    layer = smplx_lbs.SMPLXLayer(model)
+    rng = np.random.default_rng(N)
+    rows = (0.2 * rng.standard_normal((N, 265))).astype(np.float32)
+    betas = (0.5 * rng.standard_normal(layer.n_betas)).astype(np.float32)
+    nj = layer.num_joints
+    run_both(lambda p: _lib.check(lib.ts_smplx_forward(layer._h, p["betas"], 0, p["rows"], 265, 165, N, p["j"], None, _lib.stream_ptr())),
+             {"betas": (betas, F32), "rows": (rows, F32)}, {"j": ((N, nj, 3), F32)})
