@@ -77,8 +77,93 @@ def build_face(device_index, seed=0):
     return m
 
 
+def reference_greedy(pix, label, aud):
+    """The greedy harness of SURVEY.md §0.3 around the REFERENCE's `GatedPixelCNN.forward` (`gated_pixelcnn_v2.py:130-150`): one
+    full-grid forward per code position, argmax of that position's logits (the reference's own `generate` draws from torch's
+    multinomial, `:167-176`; same cost per position)."""
+    B, H = aud.shape[0], aud.shape[2]
+    x = torch.zeros((B, H, 2), dtype=torch.int64)
+    with torch.no_grad():
+        for i in range(H):
+            for j in range(2):
+                x[:, i, j] = torch.argmax(pix(x, label, aud)[:, :, i, j], dim=-1)
+    return x
+
+
+def cpu_model():
+    try:
+        return [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:                                        # noqa: BLE001
+        return "unknown"
+
+
+def cpu_baseline_reference(sds, seed, budget_s=25.0, dims=None, frames=None):
+    """kind "reference": the reference's OWN nn.Modules — `nets/spg/gated_pixelcnn_v2.py::GatedPixelCNN`, `nets/spg/vqvae_1d.py::VQVAE /
+    AudioEncoder`, lifted into oracle/_ref as hash-verified code objects where /root/reference exists (oracle/build_ref_callers.py; the
+    tree itself cannot travel) — on this box's host cores, on a bounded sample of configs[1]: VQVAE.encode of the GT poses (body + hand),
+    AudioEncoder, the greedy harness around GatedPixelCNN.forward (2 H full-grid forwards), VQVAE.decode of both code rows.
+    -> the cpu_baseline block, or None where oracle/_ref holds no modules (the caller falls back to the torch port)."""
+    import contextlib
+    import io
+    from oracle import build_ref_callers as BRC
+    from talkshow_amd import synth
+    try:
+        R = BRC.load_reference_modules()
+    except BRC.RefCallersError as e:
+        print(f"[bench] reference modules not loadable: {e}", file=sys.stderr)
+        return None
+    if R is None:
+        return None
+    d = dict(input_dim=2048, dim=256, n_layers=15, num_embeddings=2048, num_hiddens=1024)
+    d.update(dims or {})
+    T_ = FRAMES_PER_CLIP if frames is None else frames
+    H = T_ // 4
+    tt = synth.to_torch
+    with contextlib.redirect_stdout(io.StringIO()):      # the constructor prints one line per layer (gated_pixelcnn_v2.py:6-13)
+        pix = R.GatedPixelCNN(d["input_dim"], d["dim"], d["n_layers"], 4, True, True)
+    pix.load_state_dict(tt(sds["pix"]), strict=True)
+    ae = R.AudioEncoder(64, 256, 2, 256)
+    ae.load_state_dict(tt(sds["audio"]), strict=True)
+    vb = R.VQVAE(39, 64, d["num_embeddings"], d["num_hiddens"], 2, 512)
+    vb.load_state_dict(tt(sds["body"]), strict=True)
+    vh = R.VQVAE(90, 64, d["num_embeddings"], d["num_hiddens"], 2, 512)
+    vh.load_state_dict(tt(sds["hand"]), strict=True)
+    for m in (pix, ae, vb, vh):
+        m.eval()
+    threads = min(32, os.cpu_count() or 1)               # fixed pool, as for the port: these layers stop scaling well before 256 threads
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        x0, aud0, lab0 = torch.zeros((4, H, 2), dtype=torch.int64), torch.zeros((4, 256, H, 2)), torch.zeros(4, dtype=torch.int64)
+        pix(x0, lab0, aud0)
+        t0 = time.perf_counter()
+        pix(x0, lab0, aud0)
+        per_fwd4 = time.perf_counter() - t0
+    clips = int(max(1, min(32, budget_s // max(per_fwd4 / 4 * 2 * H * 1.15, 1e-3))))
+    mf, ids = synth.mfcc_features(seed, clips, T_), synth.speaker_ids(clips)
+    gt = torch.from_numpy(synth.gt_poses(seed, clips, T_))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        vb.encode(gt_poses=gt[..., :39].contiguous())                                       # the encode half of configs[1]
+        vh.encode(gt_poses=gt[..., 39:].contiguous())
+        feat = ae(torch.from_numpy(mf).transpose(1, 2), frame_num=0)                        # smplx_body_pixel.py:274
+        codes = reference_greedy(pix, torch.from_numpy(ids), feat.unsqueeze(-1).repeat(1, 1, 1, 2))
+        body, _ = vb.decode(b=clips, w=H, latents=codes[..., 0])                            # :282-285
+        hand, _ = vh.decode(b=clips, w=H, latents=codes[..., 1])
+        poses = torch.cat([body, hand], dim=1).transpose(1, 2)
+    dt = time.perf_counter() - t0
+    assert tuple(poses.shape) == (clips, 4 * H, 129)
+    return {"value": clips * T_ / dt, "unit": "frames/s", "cores": threads, "kind": "reference", "cpu": cpu_model(), "host_cpus": os.cpu_count(),
+            "sample": f"{clips} clip(s) ({T_} frames each) of configs[1] through the reference's own nn.Modules (oracle/_ref: nets/spg/gated_pixelcnn_v2.py, "
+                      f"vqvae_1d.py, vqvae_modules.py compiled where /root/reference exists): VQVAE.encode x2 + AudioEncoder + greedy harness around "
+                      f"GatedPixelCNN.forward ({2 * H} full-grid forwards) + VQVAE.decode x2, fp32, torch {torch.__version__}, {threads} threads of "
+                      f"{os.cpu_count()} host CPUs, one complete pass, {dt:.1f} s"}
+
+
 def cpu_baseline(sds, seed, budget_s=25.0):
     """The reference's algorithm (full-grid recompute per code position) on this box's host cores.
+
+    kind "reference" (`cpu_baseline_reference`) where oracle/_ref holds the reference's own modules — what this function returns
+    then (TS_BENCH_CPU_PORT=1 forces the port, the figure of rounds 1-5); else:
 
     kind "port": oracle/torch_port.py — the reference's forward()s restated on the torch CPU ops its nn.Modules dispatch
     to (pinned to the reference goldens, tests/test_oracle_golden.py); /root/reference itself cannot travel to the GPU
@@ -89,6 +174,10 @@ def cpu_baseline(sds, seed, budget_s=25.0):
     (tools/time_reference_cpu.py)."""
     from oracle import torch_port as TP
     from talkshow_amd import synth
+    if os.environ.get("TS_BENCH_CPU_PORT", "0") != "1":
+        ref_leg = cpu_baseline_reference(sds, seed, budget_s)
+        if ref_leg is not None:
+            return ref_leg
     H = FRAMES_PER_CLIP // 4
     # one full-grid PixelCNN forward at 4 clips sizes the sample.  The intra-op pool is FIXED at 32 threads (or the host's CPU
     # count if smaller): these layers stop scaling well before a 256-thread host is full (a 256-thread pool made the pass 50x

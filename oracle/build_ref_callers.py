@@ -10,7 +10,8 @@ shapes.  No reference source text is written anywhere (which is why the units ar
 names file, lifted names and hashes so that what runs can be checked against the reference tree it came from).  The files are
 raw `marshal` of ONE code object each — no pickle — and `load()` verifies every hash before unmarshalling anything.
 
-What is lifted (by AST, so that the scripts' argument parsing, dataset and renderer imports stay out):
+What is lifted (by AST, so that the scripts' argument parsing, dataset and renderer imports stay out; the four `nets/spg` files of the
+body path whole — `load_reference_modules()` — for bench.py's `cpu_baseline` kind "reference" and tests/test_reference_modules.py):
     scripts/demo.py        init_model (:30-64), infer (:158-247), the module-level `device` / `global_orient` assignments
     scripts/test_body.py   init_model (:30-56), body_loss (:98-110), test (:113-194)
     data_utils/lower_body.py, data_utils/get_j.py   whole modules (they import numpy / torch only)
@@ -35,7 +36,14 @@ UNITS = {   # unit -> (file, names to keep: None = the whole module; functions a
     "test_body": ("scripts/test_body.py", ["init_model", "body_loss", "test"]),
     "lower_body": ("data_utils/lower_body.py", None),
     "get_j": ("data_utils/get_j.py", None),
+    # the reference's own nn.Modules of the body path, whole files: bench.py's cpu_baseline (kind "reference") times THESE on the GPU
+    # box's host cores, and tests/test_reference_modules.py checks them against the committed goldens
+    "spg_gated_pixelcnn_v2": ("nets/spg/gated_pixelcnn_v2.py", None),
+    "spg_vqvae_modules": ("nets/spg/vqvae_modules.py", None),
+    "spg_wav2vec": ("nets/spg/wav2vec.py", None),
+    "spg_vqvae_1d": ("nets/spg/vqvae_1d.py", None),
 }
+SPG_PACKAGE = "_talkshow_reference_spg"      # synthetic package the spg_* units are executed in (their relative imports resolve inside it)
 
 
 class RefCallersError(RuntimeError):
@@ -134,6 +142,61 @@ def load(out_dir=OUT_DIR):
         except (EOFError, ValueError, TypeError) as e:
             raise RefCallersError(f"{unit}.code does not unmarshal: {e}")
     return units, m
+
+
+def load_reference_modules(out_dir=OUT_DIR):
+    """The reference's `nets/spg/{gated_pixelcnn_v2, vqvae_modules, wav2vec, vqvae_1d}.py` as importable modules, executed from the
+    verified code objects inside a synthetic package (`SPG_PACKAGE`), or None where nothing was built.  Third-party modules those
+    files import at the top and never use on this path (`torchvision`, `matplotlib.pyplot`) are stubbed WHILE the units execute if
+    they are not installed, and removed again.  -> types.SimpleNamespace(GatedPixelCNN, VQVAE, AudioEncoder, modules={...})."""
+    import importlib.machinery
+    import types
+    got = load(out_dir)
+    if got is None:
+        return None
+    units, _ = got
+    if SPG_PACKAGE + ".vqvae_1d" in sys.modules:
+        mods = {n: sys.modules[SPG_PACKAGE + "." + n] for n in ("gated_pixelcnn_v2", "vqvae_modules", "wav2vec", "vqvae_1d")}
+    else:
+        import transformers  # noqa: F401   (before any stub: SURVEY.md Appendix C item 1)
+        stubs = []
+        for name in ("torchvision", "torchvision.datasets", "torchvision.transforms", "matplotlib", "matplotlib.pyplot"):
+            try:
+                __import__(name)
+            except Exception:                                            # noqa: BLE001 — absent or broken: unused on this path either way
+                m = types.ModuleType(name)
+                m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+                m.__path__ = []
+                sys.modules[name] = m
+                stubs.append(name)
+        for name in stubs:                                               # `from torchvision import datasets, transforms` / `import matplotlib.pyplot as plt`
+            parent, _, child = name.rpartition(".")
+            if parent in sys.modules and child:
+                setattr(sys.modules[parent], child, sys.modules[name])
+        pkg = types.ModuleType(SPG_PACKAGE)
+        pkg.__path__ = []
+        pkg.__spec__ = importlib.machinery.ModuleSpec(SPG_PACKAGE, None, is_package=True)
+        sys.modules[SPG_PACKAGE] = pkg
+        mods = {}
+        try:
+            for n in ("gated_pixelcnn_v2", "vqvae_modules", "wav2vec", "vqvae_1d"):     # dependency order
+                m = types.ModuleType(SPG_PACKAGE + "." + n)
+                m.__package__ = SPG_PACKAGE
+                m.__spec__ = importlib.machinery.ModuleSpec(m.__name__, None)
+                sys.modules[m.__name__] = m
+                setattr(pkg, n, m)
+                exec(units["spg_" + n], m.__dict__)
+                mods[n] = m
+        except Exception as e:                                           # noqa: BLE001
+            for n in list(sys.modules):
+                if n == SPG_PACKAGE or n.startswith(SPG_PACKAGE + "."):
+                    del sys.modules[n]
+            raise RefCallersError(f"the reference's nets/spg modules do not execute here: {e!r}")
+        finally:
+            for name in stubs:
+                sys.modules.pop(name, None)
+    return types.SimpleNamespace(GatedPixelCNN=mods["gated_pixelcnn_v2"].GatedPixelCNN, VQVAE=mods["vqvae_1d"].VQVAE,
+                                 AudioEncoder=mods["vqvae_1d"].AudioEncoder, AE=mods["vqvae_1d"].AE, modules=mods)
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@ def test_reference_callers_build_here():
     import hashlib
     BRC.build()
     units, meta = BRC.load()
-    assert set(units) == {"demo", "test_body", "lower_body", "get_j"}
+    assert set(units) == {"demo", "test_body", "lower_body", "get_j", "spg_gated_pixelcnn_v2", "spg_vqvae_modules", "spg_wav2vec", "spg_vqvae_1d"}
     for unit, ent in meta["units"].items():
         assert hashlib.sha256(open(os.path.join(BRC.REF, ent["file"]), "rb").read()).hexdigest() == ent["source_sha256"]
         assert hashlib.sha256(open(os.path.join(BRC.OUT_DIR, unit + ".code"), "rb").read()).hexdigest() == ent["code_sha256"]
