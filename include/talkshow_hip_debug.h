@@ -44,7 +44,8 @@ int ts_debug_tile_weights(const float *W, int N, int K, long ldw, int epi, int g
  * `iters` times between two HIP events recorded on `stream`; tile: 0 = production heuristic, 1 = 128x128,
  * 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 with 64-deep K chunks, 6 = 160x128, 7 = 96x128; 31 / 39 / 33 = the LDS-DMA ring engine's
  * 128x128 tile with 4 / 8 waves and its 96x128 tile (conv_gemm_ring.hip), 35 / 36 = 39 / 33 with the tiles dealt to the XCDs in blocks that
- * share operands, 37 = bands (128 x 128 + 64 x 128 tiles) + dealt tiles.  *ms_out = mean launch duration in milliseconds. */
+ * share operands, 37 = bands (128 x 128 + 64 x 128 tiles) + dealt tiles, 38 = whole tiles + a stream-K band (deterministic; not bit-identical
+ * with the others).  *ms_out = mean launch duration in milliseconds. */
 int ts_op_conv1d_timed(ts_ctx *ctx, const float *x_dev, int B, int Lin, int Cin, const float *w_packed_dev,
                        const float *bias_dev, int Cout, int K, int tile, int iters, float *out_dev, float *ms_out,
                        void *stream);
@@ -66,6 +67,17 @@ int ts_op_conv_taps48_timed(ts_ctx *ctx, const float *x_dev, int B, int T, int G
  * the rows that are left) — by tile count: a last round at most half full costs half a round (csrc/conv_gemm_ring.hip::conv_gemm_ring_pick).
  * -1 on a bad argument.  No reference counterpart. */
 int ts_debug_conv_ring_pick(int M, int N, int groups);
+/* Host-only helper (no GPU needed): the stream-K plan of the ring engine for `groups` problems of M rows x N columns x K (csrc/conv_gemm_ring.hip:
+ * whole 128 x 128 tiles for the row tiles that fill whole units of 256 tiles, the rows after them as one list of (tile, 32-k stage) iterations
+ * cut into equal runs).  1 = out6 = {row tiles kept whole, row tiles in the band, dealt ids of the whole-tile region, band workgroups,
+ * stages per tile, the plan the layer gets by cost: 8 = this one, 9 / 3 / 7 = a whole-tile plan}; 0 = no stream-K plan for this shape
+ * (whole units, under one unit, runs under 4 stages); -1 = bad argument.  No reference counterpart. */
+int ts_debug_conv_sk_plan(int M, int N, int K, int groups, int *out6);
+/* Host-only: the run of band workgroup q (0 <= q < band_workgroups, a multiple of 8) over a stream-K band of `band_tiles` tiles x `stages`
+ * stages, in band-iteration units (tile * stages + stage): out4 = {first iteration, one past the last, the XCD (= q % 8) whose tiles
+ * [xcd * band_tiles / 8, (xcd + 1) * band_tiles / 8) the run lies in, the run index the kernel's owner search finds for the first iteration
+ * (= q / 8)}.  0 on success, -1 on a bad argument.  No reference counterpart. */
+int ts_debug_conv_sk_run(int band_tiles, int stages, int band_workgroups, int q, int *out4);
 
 /* Test aid: out[i] = the chain kernels' gate activation tanh(v[i]) * sigmoid(p[i]) as they compute it (v_exp_f32 / v_rcp_f32 form,
  * csrc/kernels.h::gate_act; reference: GatedActivation, gated_pixelcnn_v2.py:16-22) on n device floats. */

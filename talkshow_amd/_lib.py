@@ -77,6 +77,8 @@ SIGNATURES = {
     "ts_op_conv_taps48_timed": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, C.POINTER(C.c_float), _vp]),
     "ts_op_conv1d_strided_timed": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(C.c_float), _vp]),
     "ts_debug_pixelcnn_graphs": (_i, [_vp, _vp]),
+    "ts_debug_conv_sk_plan": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int)]),
+    "ts_debug_conv_sk_run": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int)]),
     "ts_pixelcnn_graph_captures": (C.c_long, [_vp, _vp]),
     "ts_pixelcnn_prepare": (_i, [_vp, _i, _i, _i, _vp]),
     "ts_debug_conv_ring_pick": (_i, [_i, _i, _i]),

@@ -29,6 +29,7 @@ const Knobs &knobs() {
         v.conv_deal = num("TS_CONV_DEAL", 1) != 0;
         v.conv_ring_paired = num("TS_CONV_RING_PAIRED", 1) != 0;
         v.conv_taps48 = num("TS_CONV_TAPS48", 1) != 0;
+        v.conv_sk = num("TS_CONV_SK", 1);
         v.w2v_moments = num("TS_W2V_MOMENTS", 1) != 0;
         v.vq_lds = num("TS_VQ_LDS", 1) != 0;
         v.split_xcd = num("TS_SPLIT_XCD", 8);
@@ -314,8 +315,41 @@ int ts_debug_conv_ring_pick(int M, int N, int groups) {
     p.ngroups = groups;
     ts::ConvBands bd{};
     const bool have = ts::conv_gemm_plan_bands(p, bd);
-    const int pick = ts::conv_gemm_ring_pick(p, have ? &bd : nullptr);
+    const int pick = ts::conv_gemm_ring_pick(p, have ? &bd : nullptr, nullptr);
     return pick == 3 ? 96 : (pick == 7 ? 64 : 128);
+}
+
+int ts_debug_conv_sk_plan(int M, int N, int K, int groups, int *out6) {
+    if (M < 1 || N < 1 || K < 32 || K % 32 || groups < 1 || groups > 4 || !out6) return -1;
+    ts::ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.M = M;
+    p.N = N;
+    p.Ktot = K;
+    p.ngroups = groups;
+    for (int z = 0; z < groups; ++z) {
+        p.g[z].nseg = 1;
+        p.g[z].seg[0] = ts::ConvSeg{0, 0, K, 1};
+    }
+    ts::ConvSK sk{};
+    if (!ts::conv_gemm_plan_sk(p, sk)) return 0;
+    ts::ConvBands bd{};
+    const bool have = ts::conv_gemm_plan_bands(p, bd) && bd.mt_big >= 1;
+    const int pick = ts::conv_gemm_ring_pick(p, have ? &bd : nullptr, &sk);
+    const int o[6] = {sk.mt_dp, sk.mt_sk, sk.dp8, sk.wsk, sk.stages, pick};
+    std::memcpy(out6, o, sizeof(o));
+    return 1;
+}
+
+int ts_debug_conv_sk_run(int band_tiles, int stages, int band_workgroups, int q, int *out4) {
+    if (band_tiles < 8 || stages < 1 || band_workgroups < 8 || (band_workgroups & 7) || q < 0 || q >= band_workgroups || !out4) return -1;
+    const ts::SkRuns R{band_tiles, stages, band_workgroups >> 3};
+    const int c = q & 7, r = q >> 3;
+    out4[0] = R.begin(c, r);
+    out4[1] = R.begin(c, r + 1);
+    out4[2] = c;
+    out4[3] = R.run_of(c, out4[0] < out4[1] ? out4[0] : R.tlo(c) * stages);
+    return 0;
 }
 
 int ts_debug_gate_act(const float *v_dev, const float *p_dev, float *out_dev, long n, void *stream) {

@@ -359,6 +359,11 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
         if (!conv_gemm_plan_bands(p, bd)) return launch_conv_gemm_ring(p, 5, stream);
         return launch_conv_gemm_ring_banded(p, bd, stream);
     }
+    if (tile == 38) {   // ring engine, whole tiles for the whole units of 256 + a stream-K band for the rest (falls back to the dealt plain grid)
+        ConvSK sk;
+        if (!conv_gemm_plan_sk(p, sk)) return launch_conv_gemm_ring(p, 5, stream);
+        return launch_conv_gemm_ring_sk(p, sk, stream);
+    }
     if (tile == 48 || (tile == 0 && knobs().conv_taps48 && conv_taps48_takes(p))) return launch_conv_taps48(p, stream);   // grouped 48-channel taps, unpadded (conv_taps48.hip)
     // layers that take 128 x 128 tiles run on the ring engine (same-box A/B: profiles/r05_notes/): the face generator's GEMMs, and the paired
     // body + hand layers unless TS_CONV_RING_PAIRED=0 (then: the banded launch below)
@@ -366,11 +371,19 @@ hipError_t launch_conv_gemm(const ConvParams &p_in, int tile, hipStream_t stream
         const int v = knobs().conv_ring;   // 9: the tile plan by tile count (conv_gemm_ring_pick); tiles dealt to the XCDs unless TS_CONV_DEAL=0
         if (v == 9 && knobs().conv_deal) {
             ConvBands bd;
-            const bool have = knobs().conv_bands && conv_gemm_plan_bands(p, bd);
-            const int pick = conv_gemm_ring_pick(p, have ? &bd : nullptr);
+            // a band plan without a single 128-row block in its big band (more than 512 column tiles: a very wide N x groups) is no plan:
+            // the banded launch refuses it, so it must not be offered to the pick
+            const bool have = knobs().conv_bands && conv_gemm_plan_bands(p, bd) && bd.mt_big >= 1;
+            ConvSK sk;
+            const bool have_sk = knobs().conv_sk && p.sk_ok && conv_gemm_plan_sk(p, sk);
+            const int pick = conv_gemm_ring_pick(p, have ? &bd : nullptr, have_sk ? &sk : nullptr);
+            if (pick == 8 || (have_sk && knobs().conv_sk == 2)) return launch_conv_gemm_ring_sk(p, sk, stream);
             return pick == 7 ? launch_conv_gemm_ring_banded(p, bd, stream) : launch_conv_gemm_ring(p, pick == 3 ? 6 : 5, stream);
         }
-        return launch_conv_gemm_ring(p, v == 9 ? 0 : (v == 8 ? 9 : v), stream);
+        // TS_CONV_RING: 9 = the plan by tile count (default), 8 = the 8-wave 128 x 128 tile, 1 / 3 / 5 / 6 = that variant; anything else is
+        // not a variant and means the default plan, not a launch error on every layer
+        const int variant = v == 9 ? 0 : (v == 8 ? 9 : ((v == 1 || v == 3 || v == 5 || v == 6) ? v : 0));
+        return launch_conv_gemm_ring(p, variant, stream);
     }
     if (tile == 0 && pick_tile(p) == 1) {
         const bool banded = knobs().conv_bands;   // TS_CONV_BANDS=0: plain grid (A/B, tests)

@@ -41,8 +41,11 @@ __device__ __forceinline__ void ring_glds16(const float *src, float *lds_dst) { 
 
 // one BM x BN output tile at (m0, n0) of problem / group `zidx`; smem: 2 * (BM + BN) * 32 floats of LDS (ONE object: a second
 // one makes hipcc drain vmcnt before every ds_read)
-template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void ring_tile(const ConvParams &p, const int zidx, const int m0, const int n0, float *smem) {
+// Stages [t_begin, t_end) of the tile's K walk (a stage = 32 k; the whole walk is [0, Ktot / 32)); `tail(acc, g, tp, mw, nw, li, lh)` gets the
+// accumulators: the epilogue for a whole walk (ring_tile below), a partial-sum store / fix-up for a piece of one (the stream-K band).
+template <int BM, int BN, int WM, int WN, class Tail>
+__device__ __forceinline__ void ring_tile_range(const ConvParams &p, const int zidx, const int m0, const int n0, float *smem, const int t_begin,
+                                                const int t_end, Tail tail) {
     constexpr int BK = 32;                     // stage depth (k); the ring has two slots
     constexpr int SEGS = BK / 4;               // 16-byte segments of a row per stage
     constexpr int RPB = 64 / SEGS;             // rows per LDS-DMA instruction (1 KB)
@@ -97,6 +100,21 @@ __device__ __forceinline__ void ring_tile(const ConvParams &p, const int zidx, c
     }
     int s = 0, tap = 0, cc = 0;
     int cur_len = __builtin_amdgcn_readlane(vlen, 0), cur_nt = __builtin_amdgcn_readlane(vnt, 0);
+    if (t_begin > 0) {   // seek: (segment, tap, stage inside the tap) of stage t_begin — wave-uniform scalar code, a handful of iterations
+        int rem = t_begin;
+        for (;;) {
+            const int per = cur_len / BK, tot = per * cur_nt;
+            if (rem < tot) {
+                tap = rem / per;
+                cc = rem - tap * per;
+                break;
+            }
+            rem -= tot;
+            s += 1;
+            cur_len = __builtin_amdgcn_readlane(vlen, s & 3);
+            cur_nt = __builtin_amdgcn_readlane(vnt, s & 3);
+        }
+    }
     const float *pa[NA], *pb[NB];
     auto enter_run = [&]() {   // operand pointers of the first stage of (segment s, tap); halo rows and rows beyond M read zeros
         const int sl = s & 3;
@@ -113,9 +131,11 @@ __device__ __forceinline__ void ring_tile(const ConvParams &p, const int zidx, c
     };
     enter_run();
 #pragma unroll
+    for (int j = 0; j < NA; ++j) pa[j] += cc * BK;
+#pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + (wave * NB + j) * RPB + drow;
-        pb[j] = (n < w_rows ? gw + (long)n * ldw : p.zero) + dcol(wave * NB + j);
+        pb[j] = (n < w_rows ? gw + (long)n * ldw : p.zero) + dcol(wave * NB + j) + (long)t_begin * BK;
     }
     auto advance = [&]() {   // to the next stage of the K walk
         cc += 1;
@@ -172,8 +192,8 @@ __device__ __forceinline__ void ring_tile(const ConvParams &p, const int zidx, c
     // every DMA load of this wave has landed and every LDS read it issued is done (two slots: nothing is left in flight across a barrier)
     auto wait_all = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
 
-    const int T = p.Ktot / BK;   // stages
-    // ---- prologue: stage 0 goes out and lands, its first fragments are read ----
+    const int T = t_end - t_begin;   // stages of this walk
+    // ---- prologue: the first stage goes out and lands, its first fragments are read ----
 #pragma unroll
     for (int o = 0; o < ND; ++o) dma_one(0, o);
     wait_all();
@@ -238,7 +258,17 @@ __device__ __forceinline__ void ring_tile(const ConvParams &p, const int zidx, c
     }
     stage(std::false_type{}, slot);
 
-    conv_tile_epilogue<TM, TN>(p, g, tp, acc, m0 + wm * WM, n0 + wn * WN, li, lh);   // conv_tile.h
+    tail(acc, g, tp, m0 + wm * WM, n0 + wn * WN, li, lh);
+}
+
+// one whole BM x BN output tile: the full K walk, then the epilogue (conv_tile.h)
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void ring_tile(const ConvParams &p, const int zidx, const int m0, const int n0, float *smem) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    ring_tile_range<BM, BN, WM, WN>(p, zidx, m0, n0, smem, 0, p.Ktot / 32,
+                                    [&](f32x16 (&acc)[TM][TN], const ConvGroup &g, const ConvTilePtrs &tp, int mw, int nw, int li, int lh) {
+                                        conv_tile_epilogue<TM, TN>(p, g, tp, acc, mw, nw, li, lh);
+                                    });
 }
 
 // two workgroups per CU.  XCD = false: grid (row tiles, column tiles, problems).  XCD = true: 1-D grid of 8 ceil(tiles / 8) per problem, tiles
@@ -276,6 +306,153 @@ __global__ __launch_bounds__(512, 4) void conv_ring_banded_kernel(const ConvPara
     }
 }
 
+// ---- stream-K band (the partly filled last round) -------------------------------------------------------------
+// A launch of whole tiles costs ceil(tiles / 256) tile times on 256 CUs (a workgroup alone on its CU runs at the full pipe rate): the 900
+// tiles of an N = 768 layer at M = 19 200 cost 4 where 3.52 would do.  Here the row tiles that fill whole units of 256 stay whole tiles
+// (dealt to the XCDs as before); the rows after them become ONE list of (tile, stage) iterations, cut into `wsk` equal runs, one
+// workgroup each — every CU ends up with the same number of MFMA stages.  A run covers the tail of one tile and the head of the next
+// (or a slice of one tile, or whole tiles in between).  Every PIECE of a split tile is written to p.sk_ws as a partial accumulator and
+// announced on the tile's counter; the workgroup that arrives LAST (whoever that is) sums the pieces in k order — always the same
+// order, whatever the arrival order: deterministic run to run — and runs the epilogue.  Nobody ever waits for another workgroup: no
+// spinning, nothing to deadlock, and a workgroup slowed down by a neighbour's kernel delays only its own tiles.  The last
+// arriver clears the counter, so nothing has to be reset between launches.  NOT bit-identical with the whole-tile plans (a split
+// tile is P0 + P1 (+ P2) instead of one running sum), and WHICH tiles are split depends on M: a row's bits depend on the batch it
+// rides in.  Only callers that set ConvParams::sk_ok get this plan (the face generator: tolerance-only GEMMs); the body path, whose
+// results are bit-identical across pass sizes, never does.
+//
+// Coherence: the XCDs' L2s are not coherent with each other, and an agent-scope release / acquire fence writes back / invalidates the
+// WHOLE L2 (buffer_wbl2 / buffer_inv) — the operand tiles the whole-tile workgroups next door are living on (measured: the band cost 1.2
+// tile times instead of 0.5 with fences; and sc1 write-through stores + vmcnt(0) alone are NOT a release: a reader on another XCD saw
+// stale memory).  So no tile is ever split ACROSS XCDs: the band's tile list is dealt to the 8 XCDs in whole tiles (XCD c: tiles
+// [c Ts / 8, (c + 1) Ts / 8)), each XCD's iterations are cut into wsk / 8 equal runs, and band workgroup q works on XCD q % 8 (workgroup
+// ids go round-robin over the XCDs).  All pieces of a tile then meet in ONE L2: plain stores (complete at the L2: vmcnt(0)), sc1 loads
+// (past the CU's L1), agent-scope atomics on the counter.
+__device__ __forceinline__ void sk_store_partial(f32x16 (&acc)[1][2], float *dst) {
+    f32x4 *d = reinterpret_cast<f32x4 *>(dst) + threadIdx.x;   // chunk c of thread tid at [c][tid]: a wave stores 1 KB runs (512 threads per workgroup)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[(j * 4 + q) * 512] = f32x4{acc[0][j][4 * q], acc[0][j][4 * q + 1], acc[0][j][4 * q + 2], acc[0][j][4 * q + 3]};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool FIRST>
+__device__ __forceinline__ void sk_load_partial(f32x16 (&acc)[1][2], const float *src) {
+    const float *s_ = src + threadIdx.x * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {   // four loads and the wait for them per block (the compiler cannot see an asm load's latency)
+        f32x4 v[4];
+        const float *b = s_ + h * 4 * 2048;
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+            "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+            : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+            : "v"(b), "v"(b + 2048), "v"(b + 2 * 2048), "v"(b + 3 * 2048)
+            : "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[0][h][4 * q + r] = FIRST ? v[q][r] : acc[0][h][4 * q + r] + v[q][r];
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void conv_ring_sk_kernel(const ConvParams p, const ConvSK sk) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * (128 + 128) * 32];
+    const int nt = (p.N + 127) / 128, gw = nt < 8 ? nt : 8;
+    int id = blockIdx.x, tx = 0, ty = 0;
+    const int ndp = sk.dp8 * p.ngroups;
+    const bool dp = id < ndp;
+    const SkRuns R{sk.mt_sk * nt, sk.stages, sk.wsk >> 3};
+    // a whole tile is a run of exactly one piece [0, stages) — one instance of the tile code serves both kinds of workgroup
+    int z, c = 0, r = 0, it0 = 0, it1 = sk.stages;
+    if (dp) {
+        z = id / sk.dp8;
+        if (!split_tile_of(id - z * sk.dp8, sk.mt_dp, nt, gw, tx, ty)) return;
+    } else {
+        id -= ndp;
+        z = id / sk.wsk;
+        const int q = id - z * sk.wsk;
+        c = q & 7;                                                  // = this workgroup's XCD (ndp and wsk are multiples of 8)
+        r = q >> 3;
+        it0 = R.begin(c, r);
+        it1 = R.begin(c, r + 1);
+    }
+    const int j = c * R.w8 + r;
+    float *ws = p.sk_ws + (size_t)z * sk.wsk * (2 * 128 * 128);     // two partial slots per band workgroup: [0] its run's first piece, [1] its last
+    int *counters = p.sk_flags + z * R.Ts;                          // one arrival counter per band tile
+    int hi = it1;
+    while (hi > it0) {   // the pieces of [it0, it1), one per tile, last piece first
+        int tbase = 0, tile = 0;
+        if (!dp) {
+            tile = (hi - 1) / sk.stages;
+            tbase = tile * sk.stages;
+            tx = sk.mt_dp + tile / nt;
+            ty = tile % nt;
+        }
+        const int lo = it0 > tbase ? it0 : tbase;
+        ring_tile_range<128, 128, 32, 64>(
+            p, z, tx * 128, ty * 128, smem, lo - tbase, hi - tbase,
+            [&](f32x16 (&acc)[1][2], const ConvGroup &g, const ConvTilePtrs &tp, int mw, int nw, int li, int lh) {
+                if (lo > tbase || hi - tbase < sk.stages) {   // a piece of a split tile
+                    sk_store_partial(acc, ws + (size_t)(2 * j + (it0 < tbase ? 1 : 0)) * (128 * 128));
+                    __syncthreads();                          // every thread's stores are at the L2 (and every wave is done with the ring)
+                    const int rf = R.run_of(c, tbase), rl = R.run_of(c, tbase + sk.stages - 1);
+                    int *sh = reinterpret_cast<int *>(smem);
+                    if (threadIdx.x == 0) sh[0] = __hip_atomic_fetch_add(counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    const bool last = sh[0] == rl - rf;       // the other pieces are all there
+                    __syncthreads();                          // (sh[0] is ring memory: read before the next piece's DMA)
+                    if (!last) return;
+                    if (threadIdx.x == 0) __hip_atomic_store(counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch finds it clear
+                    sk_load_partial<true>(acc, ws + (size_t)(2 * (c * R.w8 + rf) + (R.begin(c, rf) < tbase ? 1 : 0)) * (128 * 128));
+                    for (int rr = rf + 1; rr <= rl; ++rr)     // k order, whoever arrived last
+                        sk_load_partial<false>(acc, ws + (size_t)(2 * (c * R.w8 + rr) + (R.begin(c, rr) < tbase ? 1 : 0)) * (128 * 128));
+                }
+                conv_tile_epilogue<1, 2>(p, g, tp, acc, mw, nw, li, lh);
+            });
+        hi = lo;
+        if (hi > it0) __syncthreads();   // the ring's two slots are reused by the next piece
+    }
+}
+
+bool conv_gemm_plan_sk(const ConvParams &p, ConvSK &sk) {
+    if (p.zdiv > 0 || !conv_gemm_ring_takes(p) || p.ngroups < 1 || 256 % p.ngroups) return false;
+    const int MT = (p.M + 127) / 128, nt = (p.N + 127) / 128, unit = 256 / p.ngroups;
+    const long per = (long)MT * nt;                    // tiles of a problem
+    long full = per / unit * unit;                     // ... of which these make whole units of the chip
+    if (full == 0 || full == per || unit < 8) return false;
+    sk.wsk = unit;
+    sk.stages = p.Ktot / 32;
+    for (;;) {
+        sk.mt_dp = (int)(full / nt);
+        sk.mt_sk = MT - sk.mt_dp;
+        sk.dp8 = 8 * ((sk.mt_dp * nt + 7) / 8);
+        if (sk.mt_dp < 1 || sk.mt_sk < 1) return false;
+        const long I = (long)sk.mt_sk * nt * sk.stages;
+        if (I * (sk.wsk + 1) >= (1l << 31)) return false;        // the kernel cuts the runs in int arithmetic
+        if (I / sk.wsk >= 4 && sk.mt_sk * nt >= 32) return true;   // (and at least 4 tiles per XCD: the band is dealt to the XCDs in whole tiles)
+        // a few tiles over whole units (3 600 = 14 x 256 + 16): runs of under 4 stages would be all prologue — the band takes one more
+        // unit of tiles instead (runs of a little over one tile each)
+        if (full < 2 * unit) return false;
+        full -= unit;
+    }
+}
+
+hipError_t launch_conv_gemm_ring_sk(const ConvParams &p_in, const ConvSK &sk, hipStream_t stream) {
+    ConvParams p = p_in;
+    if (!p.zero) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) p.zero = skinny_zero_buffer(dev);
+    }
+    if (!p.zero || !conv_gemm_ring_takes(p) || p.zdiv > 0 || sk.mt_dp < 1 || sk.mt_sk < 1 || sk.wsk < 8 || (sk.wsk & 7) || sk.stages != p.Ktot / 32)
+        return hipErrorInvalidValue;
+    const int nt = (p.N + 127) / 128;
+    if (conv_sk_workspace(stream, (size_t)sk.wsk * p.ngroups * 2 * 128 * 128, (size_t)sk.mt_sk * nt * p.ngroups, &p.sk_ws, &p.sk_flags) != 0)
+        return hipErrorOutOfMemory;
+    hipLaunchKernelGGL(conv_ring_sk_kernel, dim3((unsigned)((sk.dp8 + sk.wsk) * p.ngroups)), dim3(512), 0, stream, p, sk);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_gemm_ring_banded(const ConvParams &p_in, const ConvBands &bd, hipStream_t stream) {
     ConvParams p = p_in;
     if (!p.zero) {
@@ -306,8 +483,15 @@ bool conv_gemm_ring_takes(const ConvParams &p) {
 //   7: bands (conv_gemm.hip's plan, `bd`): 128 x 128 tiles for the whole rounds, 64 x 128 tiles (~7 % slower per flop) for the rows that
 //      are left: FFN1 (3 600 tiles = 7.03 rounds -> 6.98 + half a round of short tiles: 715 -> 693 us) and the paired body + hand layers
 //      (2 400 tiles = 4.69 rounds -> 4 + 1.5 short ones: conv stacks of a 256-clip pass 25.7 -> 25.2 ms); ties go to the plain plans.
-// Measured: profiles/r05_notes/ring_tall_tiles.txt, face_layers_ab.txt, ring_banded_probe.txt.
-int conv_gemm_ring_pick(const ConvParams &p, const ConvBands *bd) {
+//   8: whole tiles + stream-K band (`sk`, round 6): cost = the tile list's exact share of the chip + the band's hand-over.
+// Measured: profiles/r05_notes/ring_tall_tiles.txt, face_layers_ab.txt, ring_banded_probe.txt; round 6: profiles/r06_notes/stream_k_*.txt.
+// In the face pass (profiles/r06_notes/stream_k_in_situ.txt; band forced vs off, per layer): FFN2 (K = 3 072: 96 stages) -5.8 %, the feature
+// convolutions of K = 1 536 -0.6 ... -1.6 %, K = 1 024 +1.4 %, QKV (K = 768, 2 700 tiles) -1.1 %, out-proj (K = 768, 900 tiles) +1.7 %, FFN1 +-0:
+// what the band costs — two prologues instead of one, the partial's trip through the L2, the arrival — is a fixed number of stages, so its
+// share falls with K.
+constexpr double SK_OVERHEAD_STAGES = 4.0;    // ... in rounds of 512 tiles: 4 stages' worth, i.e. 4 / (stages per tile)
+constexpr double SK_MARGIN = 0.97;            // the band must promise 3 % over the best whole-tile plan
+int conv_gemm_ring_pick(const ConvParams &p, const ConvBands *bd, const ConvSK *sk) {
     const long nt = (long)((p.N + 127) / 128) * p.ngroups;
     auto rounds = [](long tiles) {
         const long full = tiles / 512, rest = tiles - full * 512;
@@ -323,7 +507,14 @@ int conv_gemm_ring_pick(const ConvParams &p, const ConvBands *bd) {
     }
     if (bd) {   // the big band is whole rounds but for a few tiles, whose slots the short tiles take
         const double cb = bd->first_small / 512.0 * 128.0 + rounds((long)bd->mt_small * nt) * 64.0 / 0.93;
-        if (cb < 0.98 * best) pick = 7;   // within 2 % the plain plans measure as fast or faster (feature convolutions 5 / 6: 537 vs 532, 277 vs 271 us)
+        if (cb < 0.98 * best) {   // within 2 % the plain plans measure as fast or faster (feature convolutions 5 / 6: 537 vs 532, 277 vs 271 us)
+            best = cb;
+            pick = 7;
+        }
+    }
+    if (sk) {   // 8: whole tiles for the whole units of 256 + a stream-K band: the chip's share of the tile list, plus what the band's hand-over costs
+        const double cs = ((double)((p.M + 127) / 128) * nt / 512.0 + SK_OVERHEAD_STAGES / sk->stages) * 128.0;
+        if (cs < SK_MARGIN * best) pick = 8;
     }
     return pick;
 }
@@ -335,8 +526,8 @@ hipError_t launch_conv_gemm_ring(const ConvParams &p_in, int variant, hipStream_
         if (hipGetDevice(&dev) == hipSuccess) p.zero = skinny_zero_buffer(dev);
     }
     if (!p.zero || !conv_gemm_ring_takes(p)) return hipErrorInvalidValue;
-    if (variant == 0) variant = conv_gemm_ring_pick(p, nullptr);
-    if (variant == 10) variant = conv_gemm_ring_pick(p, nullptr) == 3 ? 6 : 5;   // the pick (without bands), tiles dealt to the XCDs
+    if (variant == 0) variant = conv_gemm_ring_pick(p, nullptr, nullptr);
+    if (variant == 10) variant = conv_gemm_ring_pick(p, nullptr, nullptr) == 3 ? 6 : 5;   // the pick (without bands), tiles dealt to the XCDs
     const dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.ngroups);
     auto dealt = [&](int bm) { return dim3(8 * (unsigned)(((long)((p.M + bm - 1) / bm) * grid.y + 7) / 8), 1, grid.z); };
     switch (variant) {

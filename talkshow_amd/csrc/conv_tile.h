@@ -103,7 +103,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const Co
 hipError_t launch_conv_gemm_ring(const ConvParams &p, int variant, hipStream_t stream);
 hipError_t launch_conv_gemm_ring_banded(const ConvParams &p, const ConvBands &bd, hipStream_t stream);   // tile id 37: bands (plan_bands) + dealt tiles
 bool conv_gemm_ring_takes(const ConvParams &p);   // host: every segment a multiple of the 32-deep stage
-int conv_gemm_ring_pick(const ConvParams &p, const ConvBands *bd);   // host: the plan by tile count: 9 (128 x 128), 3 (96 x 128) or, if `bd` is given, 7 (bands)
+int conv_gemm_ring_pick(const ConvParams &p, const ConvBands *bd, const ConvSK *sk);   // host: the plan by tile count: 9 (128 x 128), 3 (96 x 128), 7 (bands, if `bd` is given) or 8 (stream-K band, if `sk` is given)
 
 // grouped many-tap convolution with 48 channels per group (conv_taps48.hip: the wav2vec2 positional convolution); tile id 48
 hipError_t launch_conv_taps48(const ConvParams &p, hipStream_t stream);

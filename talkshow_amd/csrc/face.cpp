@@ -324,6 +324,7 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
     auto conv = [&](const ConvLayer &Ly, const float *x, int ldx, int Bc, int Lin, int Lout, int stride, const float *res,
                     int ldr, float *o, int ldo, int col0, int nstore, int act) -> int {
         params_for(Ly, x, ldx, Bc, Lin, Lout, stride, res, ldr, o, ldo, col0, nstore, act, &p, f->split_planes == 2);
+        p.sk_ok = 1;   // tolerance-only GEMMs (<= 1e-4 vs the reference; measured 2e-6): the ring engine may split the last unit's tiles in K
         return run_conv(ctx, p, f->split_planes ? 20 + f->split_planes : 0, s);
     };
     auto ln = [&](const float *x, int C, const LNp &q, const float *post, int relu, float *o) -> int {
@@ -384,13 +385,22 @@ int ts_face_generate(ts_face *f, const float *wav, int B, int N, int frames, con
         G.out = w.TMP.f();
         G.nseg = 1;
         G.seg[0] = ConvSeg{-(f->POSK / 2), 0, 64, f->POSK};
+        int pos_tile = f->split_planes ? 20 + f->split_planes : 0;
         if (!f->split_planes && f->pos_wd.p && ts::knobs().conv_taps48) {   // unpadded: 48-channel taps, 48 weight rows per group (conv_taps48.hip)
-            p.Ktot = f->POSK * cg;
-            p.w_zs1 = (long)cg * p.Ktot;
-            G.w = f->pos_wd.f();
-            G.seg[0].len = cg;
+            ConvParams q = p;
+            q.Ktot = f->POSK * cg;
+            q.w_zs1 = (long)cg * q.Ktot;
+            q.g[0].w = f->pos_wd.f();
+            q.g[0].seg[0].len = cg;
+            // the unpadded weights are ONLY laid out for conv_taps48: take them when that kernel takes the layer (alignment, lengths) and
+            // name it explicitly (tile 48 fails loudly on a mismatch); otherwise the padded 64-row weights + the generic engine stay (ADVICE r5:
+            // a fall-through to 64 x 64 tiles over 48-row weights would read 16 rows past the last group)
+            if (conv_taps48_takes(q)) {
+                p = q;
+                pos_tile = 48;
+            }
         }
-        TS_TRY(run_conv(ctx, p, f->split_planes ? 20 + f->split_planes : 0, s));
+        TS_TRY(run_conv(ctx, p, pos_tile, s));
     }
     TS_TRY(ln(w.TMP.f(), HID, f->enc_ln, nullptr, 0, w.H.f()));
     // ---- transformer layers (post-LN) ----

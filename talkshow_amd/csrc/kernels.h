@@ -48,6 +48,10 @@ struct ConvParams {
     const float *zero;   // >= 64 KB of zeros (filled by the launcher): where halo / padding operand pointers are parked
     int zdiv;
     long x_zs0, x_zs1, w_zs0, w_zs1, o_zs0, o_zs1, b_zs1, r_zs0, r_zs1;
+    int sk_ok;           // the caller accepts the ring engine's stream-K plan: results within fp32 rounding of the whole-tile plans, deterministic,
+                         // but a row's bits depend on M (which tiles get split).  Set by the face generator only; the body path never sets it
+    float *sk_ws;        // stream-K band of the ring engine (conv_gemm_ring.hip): partial accumulators, two 128 x 128 fp32 blocks per band workgroup,
+    int *sk_flags;       // and one arrival counter per band tile (zero between launches); set by launch_conv_gemm_ring_sk
     int w_planes;        // conv_gemm_split, 2 planes only: the weights are plane images already (split_weight_planes): no split of B in the kernel
     int xcd_tiles;       // set by launch_conv_gemm_split (0 or the column-group width): 1-D grid, tiles dealt to the XCDs in blocks that share operands
 };
@@ -58,12 +62,49 @@ struct ConvBands {
     int mt_big, mt_small, first_small, total;
 };
 
+// stream-K launch of the ring engine (conv_gemm_ring.hip), per problem: row tiles [0, mt_dp) of 128 rows as whole 128 x 128 tiles
+// (dp8 dealt workgroup ids), the mt_sk row tiles after them as ONE list of (tile, 32-k stage) iterations cut into wsk equal runs,
+// one workgroup each; `stages` = Ktot / 32
+struct ConvSK {
+    int mt_dp, mt_sk, dp8, wsk, stages;
+};
+// The band's run arithmetic, one definition for the kernel and the host-side test (ts_debug_conv_sk_run): Ts band tiles of `stages` stages;
+// XCD c holds tiles [tlo(c), tlo(c + 1)); its w8 = wsk / 8 runs cut its iterations evenly.  All in band-iteration units (tile * stages + stage).
+struct SkRuns {
+    int Ts, stages, w8;
+    __host__ __device__ int tlo(int c) const { return (int)((long)c * Ts / 8); }
+    __host__ __device__ int xcd_of_tile(int tile) const {
+        int c = (int)((long)tile * 8 / Ts);
+        if (c > 7) c = 7;
+        while (c < 7 && tlo(c + 1) <= tile) ++c;
+        while (c > 0 && tlo(c) > tile) --c;
+        return c;
+    }
+    __host__ __device__ int begin(int c, int r) const {   // first iteration of run r of XCD c (r == w8: one past its last)
+        const int base = tlo(c) * stages, Ic = (tlo(c + 1) - tlo(c)) * stages;
+        return base + (int)((long)r * Ic / w8);
+    }
+    __host__ __device__ int run_of(int c, int x) const {  // the run of XCD c that holds iteration x
+        const int base = tlo(c) * stages, Ic = (tlo(c + 1) - tlo(c)) * stages;
+        int r = (int)((long)(x - base) * w8 / Ic);
+        while (r + 1 < w8 && begin(c, r + 1) <= x) ++r;
+        while (r > 0 && begin(c, r) > x) --r;
+        return r;
+    }
+};
+
+bool conv_gemm_plan_sk(const ConvParams &p, ConvSK &sk);       // host only: false = the layer has no partly filled last unit worth splitting
+hipError_t launch_conv_gemm_ring_sk(const ConvParams &p, const ConvSK &sk, hipStream_t stream);   // tile id 38
+// host (models.cpp): per-stream scratch of the stream-K band — ws_floats floats + nflags zeroed ints, grown on demand, dropped with the stream
+int conv_sk_workspace(hipStream_t s, size_t ws_floats, size_t nflags, float **ws, int **flags);
+
 bool conv_gemm_band_plan(const ConvParams &p, ConvBands &bd);   // host only: the plan launch_conv_gemm(p, 0, ...) would use
 bool conv_gemm_plan_bands(const ConvParams &p, ConvBands &bd);  // host only: the bands of a layer given to 128 x 128 tiles (false: none — under one round, or whole rounds)
 // tile: 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128, 5 = 64x64 (BK 64), 6 = 160x128, 7 = 96x128 (for tuning / tests);
 // 31 / 39 / 33 = the LDS-DMA ring engine's 128x128 tile with 4 / 8 waves, its 96x128 tile (conv_gemm_ring.hip); 35 / 36 = 39 / 33 with the
 // tiles dealt to the XCDs in operand-sharing blocks, 37 = bands + dealt tiles; 48 = conv_taps48.hip (batched problems of 48-channel taps only)
 hipError_t launch_conv_gemm(const ConvParams &p, int tile, hipStream_t stream);
+bool conv_taps48_takes(const ConvParams &p);   // host: would tile 48 (conv_taps48.hip) take this layer as laid out?
 // the same convolution on the bf16 matrix cores with fp32 operands split into `planes` bf16 terms (2: three products, ~2^-16;
 // 3: six products, fp32 grade) — conv_gemm_split.hip; an opt-in plan for tolerance-only GEMMs (the face generator)
 hipError_t launch_conv_gemm_split(const ConvParams &p, int planes, hipStream_t stream);
@@ -206,6 +247,7 @@ struct Knobs {
     bool vq_lds = true;         // TS_VQ_LDS=0: the codebook search reads code rows from L2 per thread instead of LDS-staged tiles (tests, A/B)
     int conv_ring = 9;          // TS_CONV_RING=0|1|3|8|9: single-problem layers that take 128 x 128 tiles on conv_gemm.hip (0) / forced onto the ring engine's 128 x 128 tile with 4 (1) or 8 (8) waves or its 96 x 128 tile (3) / (9, default) 128 x 128 on 8 waves or 96 x 128 by tile count
     bool w2v_moments = true;    // TS_W2V_MOMENTS=0: conv0's GroupNorm statistics from a pass that computes the convolution (512 channels) instead of from the input's second moments (A/B, tests)
+    int conv_sk = 1;            // TS_CONV_SK=0: no stream-K band in the ring engine's plans (whole tiles only: the round-5 plans); 2: the band wherever a layer has a plan for one (A/B, tests)
     bool conv_taps48 = true;    // TS_CONV_TAPS48=0: the face generator's grouped positional conv as 64-channel windows on conv_gemm_f32's tiles instead of conv_taps48.hip (A/B, tests)
     bool conv_ring_paired = true;    // TS_CONV_RING_PAIRED=0: paired layers (two problems per launch: body + hands) on conv_gemm.hip's banded launch instead of the ring engine (A/B, tests)
     bool conv_deal = true;      // TS_CONV_DEAL=0: the ring engine's tiles as a plain (row tiles, column tiles) grid instead of dealt to the XCDs in operand-sharing blocks (A/B, tests)

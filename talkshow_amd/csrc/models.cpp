@@ -88,6 +88,29 @@ Profiler::~Profiler() {
     for (auto e : pool) (void)hipEventDestroy(e);
 }
 
+// per-stream scratch of the ring engine's stream-K band (conv_gemm_ring.hip): partial accumulators + flags.  The flags are zeroed when
+// the buffer is (re)allocated; after that every flag is cleared by the one workgroup that consumes it.
+namespace {
+struct SkWork {
+    DevBuf ws, flags;
+};
+StreamWorks<SkWork> &sk_works() {
+    static StreamWorks<SkWork> w;
+    return w;
+}
+}  // namespace
+int conv_sk_workspace(hipStream_t s, size_t ws_floats, size_t nflags, float **ws, int **flags) {
+    SkWork &w = sk_works().get(s);
+    TS_TRY(w.ws.ensure(ws_floats * sizeof(float)));
+    if (nflags * sizeof(int) > w.flags.bytes) {
+        TS_TRY(w.flags.ensure(nflags * sizeof(int)));
+        TS_HIP(hipMemsetAsync(w.flags.p, 0, w.flags.bytes, s));
+    }
+    *ws = w.ws.f();
+    *flags = w.flags.i();
+    return 0;
+}
+
 int run_conv(ts_ctx *ctx, const ConvParams &p, int tile, hipStream_t s) {
     ctx->n_launch[FAM_CONV].fetch_add(1, std::memory_order_relaxed);
     atomic_add(ctx->n_flops[FAM_CONV], conv_gemm_flops(p));

@@ -280,6 +280,9 @@ def peak_pick(x, pre_max, post_max, pre_avg, post_avg, delta, wait):
     return np.asarray(peaks, dtype=np.int64)
 
 
+_onset_warned = False
+
+
 def onset_times(wave, sr=16000, hop_length=512):
     """Onset times in seconds of a mono waveform: `librosa.onset.onset_detect(y=wave, sr=sr, units='time')` — by librosa ITSELF when
     it is importable (the reference's pin is librosa~=0.9.2; this image has none), else by the restatement above of its published
@@ -291,7 +294,13 @@ def onset_times(wave, sr=16000, hop_length=512):
         import librosa
         return np.asarray(librosa.onset.onset_detect(y=wave, sr=sr, units='time'), dtype=np.float64)
     except ImportError:
-        pass
+        global _onset_warned
+        if not _onset_warned:               # once per process: what comes back is NOT librosa's output
+            import warnings
+            warnings.warn("talkshow_amd.frontend.onset_times: librosa is not installed; onset times come from a restatement of "
+                          "librosa.onset.onset_detect whose parity with librosa ~= 0.9.2 is UNPINNED (peak_pick edge handling, STFT pad mode) — "
+                          "beat-consistency numbers computed from them may differ from the reference's", RuntimeWarning, stacklevel=2)
+            _onset_warned = True
     env = onset_strength(wave, sr, hop_length=hop_length)
     env = env - env.min()
     if not env.any():

@@ -173,6 +173,27 @@ def test_face_on_recordings(golden, name):
     assert_close_measured(f"real_audio.{t}.face_in_batch", m.run(batch, ids, frame).cpu().numpy()[5], g[t + "_out_one_hot"], 1e-4)
 
 
+def test_face_recording_inside_batch_64(golden):
+    """style.wav (exactly 10 s: 160 000 samples at 16 kHz) as clips 7 and 40 of a BASELINE configs[2] batch of 64 beside white-noise
+    clips — the shape at which the transformer GEMMs run their production plans (M = 19 200 rows: the ring engine's stream-K band on
+    FFN2, bands on FFN1, ...) — against the reference's output on the recording: zero id and one-hot id, 1e-4."""
+    from talkshow_amd.modules import FaceGenerator
+    g = golden("real_audio_face")
+    wav = _wav16("style.wav", g)
+    N, frame, spk = (int(v) for v in g["style_n"])
+    assert N == 160000 and frame == 300
+    m = FaceGenerator().cuda()
+    m.load_state_dict(synth.to_torch(synth.face_state_dict(seed=7)))
+    batch = synth.wav16(4100, 64, N)
+    ids = np.eye(4, dtype=np.float32)[np.arange(64) % 4]
+    batch[7], batch[40] = wav, wav
+    ids[7] = 0.0
+    ids[40] = np.eye(4, dtype=np.float32)[spk]
+    out = m.run(batch, ids, frame).cpu().numpy()
+    assert_close_measured("real_audio.style.face_zero_id_in_batch_64", out[7], g["style_out_zero_id"], 1e-4)
+    assert_close_measured("real_audio.style.face_one_hot_in_batch_64", out[40], g["style_out_one_hot"], 1e-4)
+
+
 def test_face_on_recordings_conv0_convolution_pass():
     """The same test with conv0's GroupNorm statistics taken from a convolution pass instead of the waveform's second moments
     (`TS_W2V_MOMENTS=0`; knobs are read once per process -> child process)."""

@@ -338,3 +338,43 @@ def test_conv_ring_tile_choice_by_tile_count():
     for M, N, G in ((19200, 1024, 2), (38400, 512, 2), (76800, 256, 2), (19200, 512, 4)):   # the paired layers of the VQ stacks at 256 clips
         assert lib.ts_debug_conv_ring_pick(M, N, G) == 64
     assert lib.ts_debug_conv_ring_pick(0, 64, 1) == -1
+
+
+def test_stream_k_band_plan_and_runs():
+    """Host side of the ring engine's stream-K plan (csrc/conv_gemm_ring.hip), no GPU needed: which layers get a band,
+    and that the band's runs (a) cover every (tile, stage) iteration exactly once, (b) are equal to within one stage inside an XCD, (c) never
+    split a tile ACROSS XCDs (the pieces of a tile meet in one L2: the XCDs' L2s are not coherent with each other), (d) give every band
+    workgroup at most one partial per slot, and that the owner search the kernel uses to find a tile's pieces agrees with the cut."""
+    import ctypes as C
+    from talkshow_amd import _lib
+    lib = _lib.load()
+    o6, o4 = (C.c_int * 6)(), (C.c_int * 4)()
+    # the wav2vec2 block GEMMs of a face batch of 64 (M = 19 200): out-proj / FFN2 (900 tiles), QKV (2 700), FFN1 (3 600 = 14 x 256 + 16)
+    assert lib.ts_debug_conv_sk_plan(19200, 768, 768, 1, o6) == 1 and list(o6)[:5] == [128, 22, 768, 256, 24] and o6[5] == 3   # K = 768: the band's fixed cost eats the gain (measured)
+    assert lib.ts_debug_conv_sk_plan(19200, 768, 3072, 1, o6) == 1 and o6[4] == 96 and o6[5] == 8
+    assert lib.ts_debug_conv_sk_plan(19200, 2304, 768, 1, o6) == 1 and list(o6)[:4] == [142, 8, 2560, 256]
+    assert lib.ts_debug_conv_sk_plan(19200, 3072, 768, 1, o6) == 1 and o6[0] * 24 + o6[1] * 24 == 3600 and o6[1] * 24 >= 256   # one more unit in the band
+    assert lib.ts_debug_conv_sk_plan(32768, 1024, 512, 1, o6) == 0            # 2 048 tiles: whole units, nothing to balance
+    assert lib.ts_debug_conv_sk_plan(2400, 1024, 512, 1, o6) == 0             # 152 tiles: under one unit
+    assert lib.ts_debug_conv_sk_plan(19200, 768, 768, 3, o6) == 0             # 256 % groups
+    for Ts, stages, W in ((132, 24, 256), (132, 96, 256), (144, 24, 256), (288, 24, 256), (33, 48, 128), (47, 7, 64), (232, 48, 256)):
+        cover = [0] * (Ts * stages)
+        per_tile_xcd = {}
+        for q in range(W):
+            assert lib.ts_debug_conv_sk_run(Ts, stages, W, q, o4) == 0
+            it0, it1, c, r = list(o4)
+            assert c == q % 8 and (it0 == it1 or r == q // 8)
+            lo_t, hi_t = c * Ts // 8, (c + 1) * Ts // 8
+            assert lo_t * stages <= it0 <= it1 <= hi_t * stages
+            per_xcd = (hi_t - lo_t) * stages / (W // 8)
+            assert abs((it1 - it0) - per_xcd) < 1.0 + 1e-9
+            for x in range(it0, it1):
+                cover[x] += 1
+                per_tile_xcd.setdefault(x // stages, set()).add(c)
+            pieces = {}
+            for x in range(it0, it1):
+                pieces.setdefault(x // stages, []).append(x)
+            partial = [t for t, xs in pieces.items() if len(xs) < stages]
+            assert len(partial) <= 2 and all(t in (min(pieces), max(pieces)) for t in partial)
+        assert set(cover) == {1}, (Ts, stages, W)
+        assert all(len(v) == 1 for v in per_tile_xcd.values())
