@@ -14,6 +14,9 @@ What is lifted (by AST, so that the scripts' argument parsing, dataset and rende
 body path whole — `load_reference_modules()` — for bench.py's `cpu_baseline` kind "reference" and tests/test_reference_modules.py):
     scripts/demo.py        init_model (:30-64), infer (:158-247), the module-level `device` / `global_orient` assignments
     scripts/test_body.py   init_model (:30-56), body_loss (:98-110), test (:113-194)
+    scripts/test_face.py   init_model (:25-53), face_loss (:78-95), test (:98-150)
+    scripts/test_vq.py     test (:27-66)
+    scripts/continuity.py  infer (:31-140), the module-level `global_orient`
     data_utils/lower_body.py, data_utils/get_j.py   whole modules (they import numpy / torch only)
 
     python oracle/build_ref_callers.py            # needs /root/reference; __graft_entry__.build() runs it where that exists
@@ -34,6 +37,9 @@ MANIFEST = os.path.join(OUT_DIR, "reference_callers.json")
 UNITS = {   # unit -> (file, names to keep: None = the whole module; functions and top-level assignments by name)
     "demo": ("scripts/demo.py", ["init_model", "infer", "device", "global_orient"]),
     "test_body": ("scripts/test_body.py", ["init_model", "body_loss", "test"]),
+    "test_face": ("scripts/test_face.py", ["init_model", "face_loss", "test"]),
+    "test_vq": ("scripts/test_vq.py", ["test"]),
+    "continuity": ("scripts/continuity.py", ["infer", "global_orient"]),
     "lower_body": ("data_utils/lower_body.py", None),
     "get_j": ("data_utils/get_j.py", None),
     # the reference's own nn.Modules of the body path, whole files: bench.py's cpu_baseline (kind "reference") times THESE on the GPU

@@ -42,7 +42,8 @@ def test_reference_callers_build_here():
     import hashlib
     BRC.build()
     units, meta = BRC.load()
-    assert set(units) == {"demo", "test_body", "lower_body", "get_j", "spg_gated_pixelcnn_v2", "spg_vqvae_modules", "spg_wav2vec", "spg_vqvae_1d"}
+    assert set(units) == {"demo", "test_body", "test_face", "test_vq", "continuity", "lower_body", "get_j", "spg_gated_pixelcnn_v2", "spg_vqvae_modules",
+                          "spg_wav2vec", "spg_vqvae_1d"}
     for unit, ent in meta["units"].items():
         assert hashlib.sha256(open(os.path.join(BRC.REF, ent["file"]), "rb").read()).hexdigest() == ent["source_sha256"]
         assert hashlib.sha256(open(os.path.join(BRC.OUT_DIR, unit + ".code"), "rb").read()).hexdigest() == ent["code_sha256"]
@@ -374,3 +375,151 @@ def test_test_body_py_loop_against_the_drop_in(tmp_path, monkeypatch):
         want = np.mean([d[name] for d in LD])
         assert abs(got[key] - want) <= 2e-4 * max(1.0, abs(want)), (key, got[key], want)
     assert np.isfinite(got["fgd_dist"]) and got["fgd_dist"] >= -1e-6 and np.isfinite(got["feat_dist"]) and got["feat_dist"] > 0
+
+
+@pytest.mark.gpu
+def test_test_face_py_loop_against_the_drop_in(tmp_path):
+    """scripts/test_face.py (VERDICT r5 missing #6): its `init_model` from a checkpoint FILE and its `test()` loop — `infer_on_audio(wav file,
+    id=speaker - 20, frame=T, am=..., am_sr=16000)`, the 265-d row it builds around the 103 face parameters, `get_joints` for both rows,
+    its own `face_loss` (jaw / landmark distances, LVD) with the `.item()` prints — lifted unchanged and run on this repo's `nets`,
+    `evaluation.metrics.LVD` and SMPL-X layer.  Expected values: the reference's `face_loss` (the lifted function itself) applied to what
+    the float64 SMPL-X oracle makes of the REFERENCE-GOLDEN face output (`face_10s`, clip 0: one-hot class 1)."""
+    import nets
+    import evaluation.metrics as metrics
+    from oracle import smplx_oracle as SO
+    from scipy.io import wavfile
+    from talkshow_amd import smplx_lbs
+    units, _ = _units()
+    gf = _golden("face_10s")
+    seed, B, N = (int(v) for v in gf["wav_seed"])
+    k, T = 0, 300
+    spk = int(np.argmax(gf["ids"][k]))
+    assert gf["ids"][k].sum() == 1.0
+    wav_path = str(tmp_path / "clip.wav")
+    wavfile.write(wav_path, 16000, synth.wav16(seed, B, N)[k].astype(np.float32))
+    face_ckpt = str(tmp_path / "face.pth")
+    torch.save({"generator": {"generator": synth.to_torch(synth.face_state_dict(seed=7))}}, face_ckpt)
+    gj = {}
+    exec(units["get_j"], gj)
+    model = SO.synthetic_model(seed=3)
+    smplx_model = _SMPLXStandIn(smplx_lbs.SMPLXLayer(model))
+    printed = []
+    ns = dict(torch=torch, np=np, s2g_face=nets.s2g_face, s2g_body_vq=nets.s2g_body_vq, s2g_body_pixel=nets.s2g_body_pixel, LVD=metrics.LVD,
+              get_joints=gj["get_joints"], tqdm=lambda it, **kw: it,
+              Wav2Vec2Processor=types.SimpleNamespace(from_pretrained=lambda *a, **kw: "am-stub"),
+              print=lambda *a: printed.append(" ".join(str(x) for x in a)))
+    exec(units["test_face"], ns)
+    config = _config(tmp_path)
+    args = argparse.Namespace(gpu=0, infer=True)
+    generator = ns["init_model"]("s2g_face", face_ckpt, args, config)
+    assert type(generator).__module__.startswith("nets.")
+    rng = np.random.default_rng(13)
+    p165 = (0.2 * rng.standard_normal((1, 165, T))).astype(np.float32)
+    exp = (0.5 * rng.standard_normal((1, 100, T))).astype(np.float32)
+    loader = [{"aud_feat": torch.zeros(1, 64, T), "poses": torch.from_numpy(p165), "expression": torch.from_numpy(exp),
+               "speaker": torch.tensor([20 + spk]), "betas": torch.zeros(1, 1, 300, dtype=torch.float64), "aud_file": [wav_path]}]
+    ns["test"](loader, generator, smplx_model, args, config)
+    got = {ln.split("=")[0].strip(): float(ln.split("=")[1]) for ln in printed if "=" in ln}
+    assert set(got) >= {"jaw_l1", "landmark_l1", "LVD"}
+    # the same quantities from the reference-golden face rows through the float64 SMPL-X oracle and the reference's own face_loss
+    face = gf["out"][k]                                                                 # (300, 103)
+    full = np.concatenate([face[:, :3], np.zeros((T, 162), np.float32), face[:, 3:]], -1)
+    poses = np.concatenate([p165[0], exp[0]], 0).T.copy()                               # (T, 265)
+    poses[:, 3:165] = full[:, 3:165]
+    gtj = SO.smplx_forward(model, np.zeros(300), poses)[0]
+    prj = SO.smplx_forward(model, np.zeros(300), full)[0]
+    want = ns["face_loss"](torch.from_numpy(gtj).float(), torch.from_numpy(poses), torch.from_numpy(prj).float(), torch.from_numpy(full))
+    for key in ("jaw_l1", "landmark_l1", "LVD"):
+        w_ = float(want[key])
+        assert abs(got[key] - w_) <= 2e-4 * max(1.0, abs(w_)), (key, got[key], w_)
+
+
+@pytest.mark.gpu
+def test_test_vq_py_loop_against_the_drop_in(tmp_path):
+    """scripts/test_vq.py::test (VERDICT r5 missing #6): `s2g_body_vq.infer_on_audio(wav, initial_pose=(1, 265, T), id, fps=30, B=1)` and
+    its 'capacity' metric (L1 between the c_index rows of the ground truth and the VQ-VAE round trip), lifted unchanged.  Expected: the same
+    metric from the REFERENCE-GOLDEN round trip (`body_vq_e2e_full`, made by the reference wrapper on the same poses)."""
+    import nets
+    units, _ = _units()
+    g = _golden("body_vq_e2e_full")
+    T = 300
+    lb, gj = {}, {}
+    exec(units["lower_body"], lb)
+    exec(units["get_j"], gj)
+    cfg = json.load(open(os.path.join(REPO, "config", "body_vq.json")))
+    from talkshow_amd.config import Object
+    config = Object(cfg)
+    w = nets.s2g_body_vq(argparse.Namespace(gpu=0, infer=True), config)
+    w.load_state_dict({"g_body": synth.to_torch(synth.vqvae_state_dict(seed=7, in_dim=39)),
+                       "g_hand": synth.to_torch(synth.vqvae_state_dict(seed=7, in_dim=90, salt=1))})
+    printed = []
+    ns = dict(torch=torch, np=np, to3d=gj["to3d"], c_index_3d=lb["c_index_3d"], tqdm=lambda it, **kw: it,
+              print=lambda *a: printed.append(" ".join(str(x) for x in a)))
+    exec(units["test_vq"], ns)
+    loader, want = [], []
+    c_index = np.asarray(g["c_index"])
+    for k in range(2):
+        p165 = np.zeros((1, 165, T), np.float32)
+        p165[0, c_index, :] = g["poses129"][k].T
+        loader.append({"aud_feat": torch.zeros(1, 64, T), "poses": torch.from_numpy(p165), "expression": torch.zeros(1, 100, T),
+                       "speaker": torch.tensor([20]), "betas": torch.zeros(1, 1, 300, dtype=torch.float64), "aud_file": ["unused.wav"]})
+        ref = g["out"][:, k * 129:(k + 1) * 129]                                         # the reference wrapper's round trip of clip k
+        want.append(np.abs(g["poses129"][k][:ref.shape[0]] - ref).sum(-1).mean())
+    ns["test"](loader, w, config)
+    got = {ln.split("=")[0].strip(): float(ln.split("=")[1]) for ln in printed if "=" in ln}
+    assert "capacity" in got
+    assert abs(got["capacity"] - float(np.mean(want))) <= 2e-4 * max(1.0, float(np.mean(want))), (got, np.mean(want))
+
+
+@pytest.mark.gpu
+def test_continuity_py_infer_against_the_drop_in(tmp_path):
+    """scripts/continuity.py::infer (VERDICT r5 missing #6), lifted unchanged: the loop over 300-frame dataset items that calls
+    `g_body.infer_on_audio(wav, initial_pose=..., norm_stats=..., txgfile=None, id=id, var=var, fps=30, continuity=True, smooth=False)` —
+    the two-part generation behind `get_mfcc_sepa` —, pads / trims to the (zero) face length, `part2full`, `get_vertices`, `np.save`, the
+    renderer's `_render_continuity`.  Wav file in (device resampler + MFCC of the first 2 s and of the rest), (300, 265) rows out.
+    Expected: the oracle's restatement of the reference's two-chunk procedure on the float64-grade host twin of the same front-end, through
+    the oracle's part2full."""
+    import nets
+    from scipy.io import wavfile
+    from talkshow_amd import frontend as fe
+    from talkshow_amd.pose_index import lower_pose_block
+    units, _ = _units()
+    lb = {}
+    exec(units["lower_body"], lb)
+    wav_path = str(tmp_path / "clip.wav")
+    wavfile.write(wav_path, 16000, synth.wav16(77, 1, 160000)[0].astype(np.float32))
+    body_ckpt = str(tmp_path / "body.pth")
+    sd_p, sd_a = synth.pixelcnn_state_dict(seed=7), synth.audioencoder_state_dict(seed=7)
+    torch.save({"generator": {"generator": synth.to_torch(sd_p), "audioencoder": synth.to_torch(sd_a)}}, body_ckpt)
+    config = _config(tmp_path)
+    args = argparse.Namespace(gpu=0, infer=True)
+    demo = {}
+    exec(units["demo"], dict(torch=torch, np=np, s2g_face=nets.s2g_face, s2g_body_vq=nets.s2g_body_vq, s2g_body_pixel=nets.s2g_body_pixel,
+                             LS3DCG=nets.LS3DCG), demo)
+    g_body = demo["init_model"]("s2g_body_pixel", body_ckpt, args, config)     # continuity.py imports diversity.py's init_model: the same function
+    rec, rendered = _SaveRecorder(), []
+    ns = dict(torch=torch, np=rec, part2full=lb["part2full"], Wav2Vec2Processor=types.SimpleNamespace(from_pretrained=lambda *a, **kw: "am-stub"),
+              get_vertices=lambda *a, **kw: (["gt-verts", "pred-verts"], None), matrix_to_axis_angle=None, rotation_6d_to_matrix=None,
+              denormalize=None)
+    exec(units["continuity"], ns)
+    T = 300
+    rng = np.random.default_rng(5)
+    loader = [{"poses": torch.from_numpy((0.2 * rng.standard_normal((1, 165, T))).astype(np.float32)),
+               "expression": torch.from_numpy((0.5 * rng.standard_normal((1, 100, T))).astype(np.float32)),
+               "speaker": torch.tensor([22]), "betas": torch.zeros(1, 1, 300, dtype=torch.float64), "aud_file": [wav_path]},
+              {"poses": torch.zeros(1, 165, 120), "expression": torch.zeros(1, 100, 120), "speaker": torch.tensor([20]),
+               "betas": torch.zeros(1, 1, 300, dtype=torch.float64), "aud_file": ["skipped: not 300 frames long"]}]
+    render = types.SimpleNamespace(_render_continuity=lambda *a, **kw: rendered.append((a, kw)))
+    ns["infer"](None, _Greedy(g_body), None, None, "exp", loader, None, torch.device("cuda", 0), None, True, None, render, args, config, (None, None))
+    assert len(rec.saved) == 1 and len(rendered) == 1 and rendered[0][0][1] == "pred-verts" and rendered[0][1] == {"frame": 60}
+    arr = rec.saved[0][1]
+    assert arr.shape == (T, 265) and arr.dtype == np.float32
+    # the reference's two-chunk procedure, restated by the oracle, on the host twin of get_mfcc_sepa
+    feat, gap = fe.get_mfcc_sepa(wav_path, fps=30, sr=22000, host=True)
+    assert gap == 1 + 44000 // 734 and feat.shape[1] == 64
+    ref, _ = O.body_pixel_infer_continuity(feat[None], gap, np.asarray([2]), sd_a, sd_p, synth.vqvae_state_dict(seed=7, in_dim=39),
+                                           synth.vqvae_state_dict(seed=7, in_dim=90, salt=1))
+    n = ref.shape[1]
+    body = np.concatenate([ref[0], np.repeat(ref[0, -1:], T - n, 0)], 0) if n < T else ref[0, :T]      # continuity.py: pad with the last frame / trim
+    want = O.assemble_full(body[None], np.zeros((1, T, 103), np.float32), lower_pose_block(False))[0]
+    np.testing.assert_allclose(arr, want, atol=1e-4, rtol=0)
