@@ -393,7 +393,7 @@ def chain_roofline(w, lib, _lib, stream, mfcc, ids, H, pmc_key):
     # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), which cannot
     # run inside this process: the recorded value of the committed summary is quoted, with its source, never passed off as live
     traffic = traffic_source = None
-    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for name in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         pmc = os.path.join(REPO, "profiles", name)
         if os.path.exists(pmc):
             rec = json.load(open(pmc)).get(pmc_key, {})
