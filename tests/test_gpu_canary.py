@@ -250,9 +250,11 @@ def test_pixelcnn_generate_and_stream_canary(hip, full_nets, B, H, H0):
                  {"c0": ((B, h1, 2), I64), "c1": ((B, H - h1, 2), I64)})
 
 
-@pytest.mark.parametrize("B,N,frames", [(1, 16001, 30), (3, 47999, 89), (2, 160000, 300), (5, 32033, 60), (1, 400, 1)])
+@pytest.mark.parametrize("B,N,frames", [(1, 16001, 30), (3, 47999, 89), (2, 160000, 300), (5, 32033, 60), (1, 400, 1), (64, 160000, 300)])
 def test_face_generate_canary(hip, B, N, frames):
-    """Odd sample counts (conv frame counts 49 .. 499 that are ragged against every tile), with and without the hidden-state output."""
+    """Odd sample counts (conv frame counts 49 .. 499 that are ragged against every tile), with and without the hidden-state output; the
+    last case is BASELINE configs[2]'s batch of 64: the shape at which FFN2 runs the ring engine's stream-K band (partials and counters in
+    library scratch, outputs between red zones)."""
     import bench
     _lib, lib, ctx = hip
     m = test_face_generate_canary.m = getattr(test_face_generate_canary, "m", None) or bench.build_face(0)
