@@ -833,7 +833,8 @@ def run_contract(job, dist, world, rank, steps, warmup, clock=time.perf_counter,
     ever waits in a collective for them.  Returns (seconds, compute seconds on this rank, exchange info or None).
     `repeats` > 1 times that same bracketed region `repeats` times back to back in the same warm state (each one EXACTLY `steps`
     steps, each with its own barriers and MAX over ranks) and returns the MEDIAN region as `seconds`; every region's time and this
-    rank's host CPU seconds inside it land in `job.contract_runs` = {"runs_ms": [...], "host_cpu_s": [...], "median_index": i}
+    rank's host CPU seconds inside it (whole region, and the part until `run_steps` returned = queueing) land in `job.contract_runs` =
+    {"runs_ms": [...], "host_cpu_s": [...], "host_enqueue_cpu_s": [...], "host_enqueue_wall_s": [...], "median_index": i}
     (one 0.12 s shot cannot adjudicate a 2 % change).
     `collectives=True` takes the N > 1 code path at world 1 too (TS_BENCH_FORCE_COLLECTIVES=1: the RCCL plumbing check that one
     metered GPU allows — process group on the `nccl` backend, barriers, the all-gather, the MAX all-reduce)."""
@@ -858,6 +859,7 @@ def run_contract(job, dist, world, rank, steps, warmup, clock=time.perf_counter,
         c0 = cpu_clock()
         t0 = clock()
         job.run_steps(steps)
+        cpu_enq, t_enq = cpu_clock() - c0, clock() - t0      # the launching thread is back: everything is queued (the sync below busy-waits)
         job.sync()
         t_compute = clock() - t0
         info = None
@@ -873,12 +875,13 @@ def run_contract(job, dist, world, rank, steps, warmup, clock=time.perf_counter,
             tmax = job.scalar(dt)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        runs.append((dt, t_compute, info, cpu))
+        runs.append((dt, t_compute, info, cpu, cpu_enq, t_enq))
         if end:
             end()
     order = sorted(range(len(runs)), key=lambda i: runs[i][0])
     mid = order[len(order) // 2]             # the median region (the upper one of an even count); every rank picks the same index
-    job.contract_runs = {"runs_ms": [r[0] * 1e3 for r in runs], "host_cpu_s": [r[3] for r in runs], "median_index": mid}
+    job.contract_runs = {"runs_ms": [r[0] * 1e3 for r in runs], "host_cpu_s": [r[3] for r in runs], "host_enqueue_cpu_s": [r[4] for r in runs],
+                         "host_enqueue_wall_s": [r[5] for r in runs], "median_index": mid}
     return runs[mid][0], runs[mid][1], runs[mid][2]
 
 
@@ -921,6 +924,10 @@ def finish(job, dist, world, rank, steps, warmup, dt, info, emit=print, collecti
         out["runs_spread"] = (max(cr["runs_ms"]) - min(cr["runs_ms"])) / cr["runs_ms"][cr["median_index"]]
         out["host_cpu_s"] = cr["host_cpu_s"][cr["median_index"]]
         out["host_cpu_per_wall"] = out["host_cpu_s"] / dt
+        # ... of which until run_steps() returned, i.e. queueing the region's work (launches, graph replays, device copies); the rest is the
+        # runtime's busy-wait inside the closing synchronize.  This is the figure eight ranks on one host compete with.
+        out["host_enqueue_cpu_s"] = cr["host_enqueue_cpu_s"][cr["median_index"]]
+        out["host_enqueue_wall_s"] = cr["host_enqueue_wall_s"][cr["median_index"]]
     if getattr(job, "host_affinity", None) is not None:
         out["host_affinity"] = job.host_affinity
     out.update(check)

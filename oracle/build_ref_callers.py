@@ -17,6 +17,7 @@ body path whole — `load_reference_modules()` — for bench.py's `cpu_baseline`
     scripts/test_face.py   init_model (:25-53), face_loss (:78-95), test (:98-150)
     scripts/test_vq.py     test (:27-66)
     scripts/continuity.py  infer (:31-140), the module-level `global_orient`
+    scripts/diversity.py   init_model (:30-64), get_vertices (:122-152), infer (:158-294), `global_orient`
     data_utils/lower_body.py, data_utils/get_j.py   whole modules (they import numpy / torch only)
 
     python oracle/build_ref_callers.py            # needs /root/reference; __graft_entry__.build() runs it where that exists
@@ -40,6 +41,7 @@ UNITS = {   # unit -> (file, names to keep: None = the whole module; functions a
     "test_face": ("scripts/test_face.py", ["init_model", "face_loss", "test"]),
     "test_vq": ("scripts/test_vq.py", ["test"]),
     "continuity": ("scripts/continuity.py", ["infer", "global_orient"]),
+    "diversity": ("scripts/diversity.py", ["init_model", "get_vertices", "infer", "global_orient"]),
     "lower_body": ("data_utils/lower_body.py", None),
     "get_j": ("data_utils/get_j.py", None),
     # the reference's own nn.Modules of the body path, whole files: bench.py's cpu_baseline (kind "reference") times THESE on the GPU

@@ -42,7 +42,7 @@ def test_reference_callers_build_here():
     import hashlib
     BRC.build()
     units, meta = BRC.load()
-    assert set(units) == {"demo", "test_body", "test_face", "test_vq", "continuity", "lower_body", "get_j", "spg_gated_pixelcnn_v2", "spg_vqvae_modules",
+    assert set(units) == {"demo", "test_body", "test_face", "test_vq", "continuity", "diversity", "lower_body", "get_j", "spg_gated_pixelcnn_v2", "spg_vqvae_modules",
                           "spg_wav2vec", "spg_vqvae_1d"}
     for unit, ent in meta["units"].items():
         assert hashlib.sha256(open(os.path.join(BRC.REF, ent["file"]), "rb").read()).hexdigest() == ent["source_sha256"]
@@ -523,3 +523,72 @@ def test_continuity_py_infer_against_the_drop_in(tmp_path):
     body = np.concatenate([ref[0], np.repeat(ref[0, -1:], T - n, 0)], 0) if n < T else ref[0, :T]      # continuity.py: pad with the last frame / trim
     want = O.assemble_full(body[None], np.zeros((1, T, 103), np.float32), lower_pose_block(False))[0]
     np.testing.assert_allclose(arr, want, atol=1e-4, rtol=0)
+
+
+class _SMPLXVerticesStandIn(_SMPLXStandIn):
+    """The per-frame call shape of `scripts/diversity.py::get_vertices` / `scripts/demo.py::get_vertices`: one row in, an object with
+    `.vertices (1, V, 3)` and `.body_pose (1, 63)` out, on this repo's device SMPL-X layer (built with_vertices=True)."""
+
+    def __call__(self, betas, expression, jaw_pose, leye_pose, reye_pose, global_orient, body_pose, left_hand_pose, right_hand_pose,
+                 return_verts=True):
+        rows = torch.cat([jaw_pose, leye_pose, reye_pose, global_orient, body_pose, left_hand_pose, right_hand_pose, expression],
+                         dim=-1).to(torch.float32)
+        joints, verts = self.layer.vertices(betas.to(torch.float32), rows)
+        return types.SimpleNamespace(vertices=verts, joints=joints, body_pose=body_pose)
+
+
+@pytest.mark.gpu
+def test_diversity_py_infer_against_the_drop_in(tmp_path, monkeypatch):
+    """scripts/diversity.py (VERDICT r5 missing #6), lifted unchanged: `init_model` from checkpoint files, `infer` — the loop over 300-frame
+    dataset items with `g_face.infer_on_audio(wav, initial_pose=..., norm_stats=None, w_pre=False, frame=None, am=..., am_sr=...)` and
+    `g_body.infer_on_audio(wav, initial_pose=..., norm_stats=..., txgfile=None, id=id, fps=30, w_pre=False)`, `part2full` / `poses2pred`,
+    `np.save`, the renderer — and its own `get_vertices` (one SMPL-X call per frame) on this repo's SMPL-X layer.  The saved (300, 265)
+    rows must be the reference-golden body poses + face parameters through the oracle's part2full; the vertices the per-frame loop
+    returns must be the float64 oracle's."""
+    import nets
+    import nets.smplx_body_pixel as bp
+    from oracle import smplx_oracle as SO
+    from scipy.io import wavfile
+    from talkshow_amd import smplx_lbs
+    from talkshow_amd.pose_index import lower_pose_block
+    units, _ = _units()
+    gb, gf = _golden("body_e2e_full"), _golden("face_10s")
+    k, T = 1, 300                                                     # golden clip 1: speaker id 1 (body), zero identity (face)
+    seed, B, N = (int(v) for v in gf["wav_seed"])
+    wav_path = str(tmp_path / "clip.wav")
+    wavfile.write(wav_path, 16000, synth.wav16(seed, B, N)[k].astype(np.float32))
+    body_ckpt, face_ckpt = str(tmp_path / "body.pth"), str(tmp_path / "face.pth")
+    torch.save({"generator": {"generator": synth.to_torch(synth.pixelcnn_state_dict(seed=7)),
+                              "audioencoder": synth.to_torch(synth.audioencoder_state_dict(seed=7))}}, body_ckpt)
+    torch.save({"generator": {"generator": synth.to_torch(synth.face_state_dict(seed=7))}}, face_ckpt)
+    monkeypatch.setattr(bp, "get_mfcc_ta", lambda *a, **kw: gb["mfcc"][k].copy())     # as in the demo test: the golden is defined on given rows
+    lb = {}
+    exec(units["lower_body"], lb)
+    rec, rendered = _SaveRecorder(), []
+    ns = dict(torch=torch, np=rec, s2g_face=nets.s2g_face, s2g_body_vq=nets.s2g_body_vq, s2g_body_pixel=nets.s2g_body_pixel, LS3DCG=nets.LS3DCG,
+              part2full=lb["part2full"], poses2pred=lb["poses2pred"], Wav2Vec2Processor=types.SimpleNamespace(from_pretrained=lambda *a, **kw: "am-stub"),
+              matrix_to_axis_angle=None, rotation_6d_to_matrix=None, denormalize=None)
+    exec(units["diversity"], ns)
+    config = _config(tmp_path)
+    args = argparse.Namespace(gpu=0, infer=True)
+    g_body = ns["init_model"]("s2g_body_pixel", body_ckpt, args, config)
+    g_face = ns["init_model"]("s2g_face", face_ckpt, args, config)
+    model = SO.synthetic_model(seed=3)
+    smplx_model = _SMPLXVerticesStandIn(smplx_lbs.SMPLXLayer(model, with_vertices=True))
+    rng = np.random.default_rng(21)
+    p165 = (0.2 * rng.standard_normal((1, 165, T))).astype(np.float32)
+    exp = (0.5 * rng.standard_normal((1, 100, T))).astype(np.float32)
+    loader = [{"poses": torch.from_numpy(p165), "expression": torch.from_numpy(exp), "speaker": torch.tensor([20 + int(gb["ids"][k])]),
+               "betas": torch.zeros(1, 1, 300, dtype=torch.float64), "aud_file": [wav_path]}]
+    render = types.SimpleNamespace(_render_sequences=lambda *a, **kw: rendered.append((a, kw)))
+    ns["infer"](None, _Greedy(g_body), g_face, None, "exp", loader, None, torch.device("cuda", 0), None, True, smplx_model, render, args, config)
+    assert len(rec.saved) == 1 and len(rendered) == 1
+    arr = rec.saved[0][1]
+    want = O.assemble_full(gb["poses"][k][None], gf["out"][k][None], lower_pose_block(False))[0]
+    assert arr.shape == (T, 265)
+    np.testing.assert_allclose(arr, want, atol=1e-4, rtol=0)
+    # what get_vertices handed the renderer: [prediction] vertices, one SMPL-X call per frame; against the float64 oracle on the expected rows
+    verts = rendered[0][0][1]
+    assert len(verts) == 1 and verts[0].shape[0] == T
+    ref_v = SO.smplx_forward(model, np.zeros(300), want[:8])[1]
+    np.testing.assert_allclose(verts[0][:8], ref_v, atol=2e-4, rtol=0)
