@@ -131,6 +131,31 @@ def test_body_on_recordings_wav_in(golden, tmp_path, name):
     assert_close_measured(f"real_audio.{t}.poses_wav_in", poses[0], g[t + "_poses"], 1e-4)
 
 
+def test_stochastic_decode_on_a_recording_vs_oracle(golden):
+    """configs[3] on real speech: the reference's audio-encoder output for french.wav (golden) -> device PixelCNN decode with INJECTED
+    uniforms and with the device Philox stream, against the oracle's full-grid `pixelcnn_generate(uniforms=...)` (the reference's
+    `generate`, `gated_pixelcnn_v2.py:152-177`, with an inverse-CDF draw): all 144 draws equal, and they are draws (they differ from greedy)."""
+    from oracle import talkshow_oracle as O
+    from talkshow_amd import _lib
+    from talkshow_amd.modules import GatedPixelCNN
+    g = golden("real_audio_body")
+    aud = g["french_aud_feat"][None]                                              # (1, 72, 256): reference AudioEncoder on the recording's rows
+    H = aud.shape[1]
+    sd = synth.pixelcnn_state_dict(seed=7)
+    m = GatedPixelCNN(2048, 256, 15, 4, True, True).cuda()
+    m.load_state_dict(synth.to_torch(sd))
+    label = np.asarray([3], np.int64)
+    u = O.philox_uniforms(2024, 7, 1, H)
+    got_u, _ = m.run(label, aud, mode=_lib.TS_SAMPLE_UNIFORMS, uniforms=u)
+    got_p, _ = m.run(label, aud, mode=_lib.TS_SAMPLE_PHILOX, seed=2024, clip_index0=7)
+    np.testing.assert_array_equal(got_p.cpu().numpy(), got_u.cpu().numpy())       # device Philox == oracle Philox
+    ref = O.pixelcnn_generate(label, np.repeat(aud.transpose(0, 2, 1)[:, :, :, None], 2, axis=3), sd, 15, H, uniforms=u)
+    diff = int((got_u.cpu().numpy() != ref).sum())
+    print(f"\nstochastic decode on french.wav: draws equal to the oracle {ref.size - diff} / {ref.size}")
+    assert diff == 0
+    assert not np.array_equal(ref[0], g["french_codes"][3].astype(np.int64))
+
+
 def _wav16(name, g):
     """The face golden's input: the 16 kHz samples whose sha256 the golden stores.  The side file written at build time, else
     regenerated here by the host twin; anything that does not hash to the golden's input is not used."""
