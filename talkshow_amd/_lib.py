@@ -11,7 +11,9 @@ import numpy as np
 import torch  # noqa: F401  (loads libamdhip64 before ours)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtalkshow_hip.so")
+# TS_LIB_PATH: another build of the same library (the AddressSanitizer build of `make asan`, an A/B build of tools/ab_libs.sh); it must
+# export every symbol of include/*.h like the default one (load() checks)
+LIB_PATH = os.environ.get("TS_LIB_PATH") or os.path.join(_HERE, "lib", "libtalkshow_hip.so")
 
 TS_SAMPLE_GREEDY, TS_SAMPLE_UNIFORMS, TS_SAMPLE_PHILOX, TS_TEACHER_FORCED = 0, 1, 2, 3
 
