@@ -297,7 +297,10 @@ def test_arbitrary_clip_lengths_bounded_graph_cache(hip):
     assert late < 1.5 * early, f"per-row wall time grew from {early * 1e6:.1f} to {late * 1e6:.1f} us"
     m1, m2, m3 = (float(np.median(w_)) for w_ in wall)
     print(f"\nper-row wall time, median over 120 lengths: pass 1 {m1 * 1e6:.1f} us, pass 2 {m2 * 1e6:.1f} us, pass 3 {m3 * 1e6:.1f} us; captures {caps}")
-    assert m2 < 1.25 * m1 and m3 < 1.25 * m1 and max(wall[2]) < 4 * m1, "a repeated pass over many lengths must stay flat"
+    # a repeated pass over many lengths stays flat: in the median, and length by length against the same length's first pass (a call that
+    # captured a length-sized graph would cost tens of milliseconds: hundreds of times a chunked call)
+    ratio = np.asarray(wall[2]) / np.maximum(np.asarray(wall[0]), 1e-9)
+    assert m2 < 1.25 * m1 and m3 < 1.25 * m1 and float(np.median(ratio)) < 1.25 and float(ratio.max()) < 5.0, (m1, m2, m3, float(ratio.max()))
     # a HOT shape: the same length three times in a row -> whole-call graph on the third call (one capture), same bits
     H = lengths[0]
     c0 = m.graph_captures()
