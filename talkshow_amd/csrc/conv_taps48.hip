@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, 4) void conv_taps48_kernel(const ConvParams p)
         for (int r = 0; r < 4; ++r) {
             float u = acc[b][r] + bv[r];
             if (tp.res && !p.res_after_act) u += rv[r];
-            if (p.act == 3) u = 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
+            if (p.act == 3) u = gelu_fast(u);
             if (tp.res && p.res_after_act) u += rv[r];
             v[r] = u;
         }

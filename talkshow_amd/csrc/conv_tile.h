@@ -47,7 +47,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvParams &p, const Co
         if (gres && !p.res_after_act) v += rvv;
         if (p.act == 1) v = v >= 0.f ? v : v * 0.2f;
         else if (p.act == 2) v = v > 0.f ? v : 0.f;
-        else if (p.act == 3) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        else if (p.act == 3) v = gelu_fast(v);   // kernels.h
         if (gres && p.res_after_act) v += rvv;
         return v;
     };

@@ -14,7 +14,7 @@ namespace ts {
 
 constexpr int C0_TB = 128;   // output frames per block in the conv0 kernels
 
-__device__ inline float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ inline float gelu_erf(float v) { return gelu_fast(v); }   // kernels.h: libm's erf algorithm, branch-free
 
 // partial sums of conv0 output per (clip, time block, channel): grid (tblocks, B), 256 threads x 2 channels
 __global__ __launch_bounds__(256) void w2v_conv0_stats_kernel(const float *__restrict__ wav, int N, int L0,

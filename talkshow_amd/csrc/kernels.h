@@ -266,6 +266,32 @@ struct Knobs {
 };
 const Knobs &knobs();
 
+// GELU(x) = x / 2 (1 + erf(x / sqrt 2)) for the conv epilogues of the face generator (reference: torch's exact-erf GELU behind the HF wav2vec2
+// layers of nets/spg/wav2vec.py).  libm's erff is two branches (|x| < 1: an odd polynomial; else 1 - exp(-poly)) with expf's own range
+// reduction: ~45 VALU instructions plus exec-mask juggling per element, and on the ring engine's 8-wave tiles it is NOT hidden — measured
+// (tools/gelu_cost.py): +42 us on a 692 us FFN1, +92 us on a 1.04 ms feature-convolution shape.  Here both pieces of the same algorithm with
+// the same coefficients run branch-free (v_cndmask) and the exponential is one v_exp_f32: ~22 instructions, |error| <= 9e-8 (1 ulp of erf)
+// against float64 over [-6, 6] — the face's distance from the reference does not move (2e-6).
+__device__ __forceinline__ float erf_fast(float x) {
+    const float a = __builtin_fabsf(x), t = a * a;
+    float p = __builtin_fmaf(t, -0.000561801774892956f, 0.004913816228508949f);
+    p = __builtin_fmaf(t, p, -0.026707515120506287f);
+    p = __builtin_fmaf(t, p, 0.11280010640621185f);
+    p = __builtin_fmaf(t, p, -0.37612295150756836f);
+    p = __builtin_fmaf(t, p, 0.12837910652160645f);
+    const float r1 = __builtin_fmaf(a, p, a);                       // |x| < 1
+    float q = __builtin_fmaf(a, 1.699881067906972e-05f, -0.00037867785431444645f);
+    q = __builtin_fmaf(a, q, 0.003857815871015191f);
+    q = __builtin_fmaf(a, q, -0.024181697517633438f);
+    q = __builtin_fmaf(a, q, 0.10666826367378235f);
+    q = __builtin_fmaf(a, q, 0.6349332928657532f);
+    q = __builtin_fmaf(a, q, 0.12868940830230713f);
+    q = __builtin_fmaf(a, q, a);
+    const float r2 = 1.0f - __builtin_amdgcn_exp2f(-1.4426950408889634f * q);   // |x| >= 1; exp2 of a large negative number flushes to 0
+    return __builtin_copysignf(a < 1.0f ? r1 : r2, x);
+}
+__device__ __forceinline__ float gelu_fast(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
+
 // tanh(v) * sigmoid(p) of GatedActivation (gated_pixelcnn_v2.py:16-22) on the hardware exponential and reciprocal (v_exp_f32,
 // v_rcp_f32: 1 ulp each): tanh(v) = 1 - 2 / (1 + e^(2v)), sigmoid(p) = 1 / (1 + e^(-p)) — 10 instructions per gate value where
 // tanhf + expf + a division took ~45 (8 values per lane in the wide kernel's epilogue: half of its VALU instructions, on the
