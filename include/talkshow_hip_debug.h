@@ -77,6 +77,9 @@ int ts_debug_conv_sk_plan(int M, int N, int K, int groups, int *out6);
  * stages, in band-iteration units (tile * stages + stage): out4 = {first iteration, one past the last, the XCD (= q % 8) whose tiles
  * [xcd * band_tiles / 8, (xcd + 1) * band_tiles / 8) the run lies in, the run index the kernel's owner search finds for the first iteration
  * (= q / 8)}.  0 on success, -1 on a bad argument.  No reference counterpart. */
+/* 1 if the current device passed the stream-K band's hardware check (workgroup ids of equal residue mod 8 share an XCD: probed once by
+ * ts_ctx_create), 0 if not or if no context was created yet: then no layer gets a stream-K plan. */
+int ts_debug_conv_sk_supported(void);
 int ts_debug_conv_sk_run(int band_tiles, int stages, int band_workgroups, int q, int *out4);
 
 /* Test aid: out[i] = the chain kernels' gate activation tanh(v[i]) * sigmoid(p[i]) as they compute it (v_exp_f32 / v_rcp_f32 form,

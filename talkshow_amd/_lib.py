@@ -81,6 +81,7 @@ SIGNATURES = {
     "ts_debug_pixelcnn_graphs": (_i, [_vp, _vp]),
     "ts_debug_conv_sk_plan": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int)]),
     "ts_debug_conv_sk_run": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int)]),
+    "ts_debug_conv_sk_supported": (_i, []),
     "ts_pixelcnn_graph_captures": (C.c_long, [_vp, _vp]),
     "ts_pixelcnn_prepare": (_i, [_vp, _i, _i, _i, _vp]),
     "ts_debug_conv_ring_pick": (_i, [_i, _i, _i]),

@@ -332,7 +332,7 @@ int ts_debug_conv_sk_plan(int M, int N, int K, int groups, int *out6) {
         p.g[z].seg[0] = ts::ConvSeg{0, 0, K, 1};
     }
     ts::ConvSK sk{};
-    if (!ts::conv_gemm_plan_sk(p, sk)) return 0;
+    if (!ts::conv_gemm_plan_sk_shape(p, sk)) return 0;
     ts::ConvBands bd{};
     const bool have = ts::conv_gemm_plan_bands(p, bd) && bd.mt_big >= 1;
     const int pick = ts::conv_gemm_ring_pick(p, have ? &bd : nullptr, &sk);
@@ -340,6 +340,8 @@ int ts_debug_conv_sk_plan(int M, int N, int K, int groups, int *out6) {
     std::memcpy(out6, o, sizeof(o));
     return 1;
 }
+
+int ts_debug_conv_sk_supported(void) { return ts::conv_sk_supported() ? 1 : 0; }
 
 int ts_debug_conv_sk_run(int band_tiles, int stages, int band_workgroups, int q, int *out4) {
     if (band_tiles < 8 || stages < 1 || band_workgroups < 8 || (band_workgroups & 7) || q < 0 || q >= band_workgroups || !out4) return -1;

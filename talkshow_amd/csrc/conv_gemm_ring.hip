@@ -415,7 +415,41 @@ __global__ __launch_bounds__(512, 4) void conv_ring_sk_kernel(const ConvParams p
     }
 }
 
-bool conv_gemm_plan_sk(const ConvParams &p, ConvSK &sk) {
+// The band's correctness rests on ONE hardware fact: workgroups of a 1-D grid go to the XCDs round-robin by id, so that band workgroups with
+// equal id % 8 share an L2.  ts_ctx_create checks it once per device (a 2 048-workgroup probe reads HW_REG_XCC_ID); where it does not hold
+// (another partition mode or part), no layer gets a stream-K plan: whole tiles only.
+__global__ void xcc_probe_kernel(int *out) {
+    if (threadIdx.x == 0) {
+        unsigned v;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        out[blockIdx.x] = (int)(v & 0xf);
+    }
+}
+static int g_sk_map_ok[16];   // per device: 0 unknown, 1 ids of equal residue mod 8 share an XCD, -1 they do not
+hipError_t conv_sk_probe_xcd_map(int device) {
+    if (device < 0 || device >= 16 || g_sk_map_ok[device]) return hipSuccess;
+    constexpr int N = 2048;
+    int *d = nullptr, h[N];
+    hipError_t e = hipMalloc(&d, N * sizeof(int));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(N), dim3(64), 0, nullptr, d);
+    e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return e;
+    bool ok = true;
+    for (int i = 8; i < N; ++i) ok = ok && h[i] == h[i & 7];
+    g_sk_map_ok[device] = ok ? 1 : -1;
+    return hipSuccess;
+}
+bool conv_sk_supported() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && g_sk_map_ok[dev] == 1;
+}
+
+bool conv_gemm_plan_sk(const ConvParams &p, ConvSK &sk) { return conv_sk_supported() && conv_gemm_plan_sk_shape(p, sk); }
+
+// the plan as a function of the layer's shape alone (host-side tests call this one: no device needed)
+bool conv_gemm_plan_sk_shape(const ConvParams &p, ConvSK &sk) {
     if (p.zdiv > 0 || !conv_gemm_ring_takes(p) || p.ngroups < 1 || 256 % p.ngroups) return false;
     const int MT = (p.M + 127) / 128, nt = (p.N + 127) / 128, unit = 256 / p.ngroups;
     const long per = (long)MT * nt;                    // tiles of a problem

@@ -93,7 +93,10 @@ struct SkRuns {
     }
 };
 
-bool conv_gemm_plan_sk(const ConvParams &p, ConvSK &sk);       // host only: false = the layer has no partly filled last unit worth splitting
+hipError_t conv_sk_probe_xcd_map(int device);                   // host, once per device (ts_ctx_create): do workgroup ids of equal residue mod 8 share an XCD?
+bool conv_sk_supported();                                       // ... the answer for the current device (false before the probe ran)
+bool conv_gemm_plan_sk_shape(const ConvParams &p, ConvSK &sk); // host only: the plan by shape (no device needed)
+bool conv_gemm_plan_sk(const ConvParams &p, ConvSK &sk);       // host only: ... where the device supports it: false = the layer has no partly filled last unit worth splitting
 hipError_t launch_conv_gemm_ring_sk(const ConvParams &p, const ConvSK &sk, hipStream_t stream);   // tile id 38
 // host (models.cpp): per-stream scratch of the stream-K band — ws_floats floats + nflags zeroed ints, grown on demand, dropped with the stream
 int conv_sk_workspace(hipStream_t s, size_t ws_floats, size_t nflags, float **ws, int **flags);

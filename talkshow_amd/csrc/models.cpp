@@ -662,6 +662,7 @@ int ts_ctx_create(int device, ts_ctx **out) {
     const int m1 = -1;
     TS_TRY(c->neg1.upload(&m1, sizeof(int)));
     TS_HIP(ts::skinny_init(device));
+    TS_HIP(ts::conv_sk_probe_xcd_map(device));   // the stream-K band's one hardware assumption, checked once (conv_gemm_ring.hip)
     *out = c.release();
     return 0;
 }

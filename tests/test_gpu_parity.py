@@ -109,6 +109,7 @@ def test_conv_stream_k_band(hip):
     band takes one more unit (runs longer than a tile); deterministic — the same bits run after run, with ANOTHER input launched in between
     (a partial read stale from the previous launch cannot pass as the right value); red zones around the output intact."""
     _lib, lib, ctx = hip
+    assert lib.ts_debug_conv_sk_supported() == 1, "MI355X: workgroup ids of equal residue mod 8 must share an XCD (probed by ts_ctx_create)"
     rng = np.random.default_rng(79)
     for B, L, Cin, Cout, K in ((64, 300, 768, 768, 1), (64, 300, 512, 384, 3), (64, 300, 256, 3072, 1)):
         o6 = (C.c_int * 6)()
