@@ -577,6 +577,33 @@ def main():
                         f"{tag}_margin": m.astype(np.float32), f"{tag}_pose_id": np.asarray(spk), f"{tag}_poses": poses.numpy()[spk]})
         save("real_audio_body", **out)
 
+    # ---- 7a. a SECOND set of weights on a recording (seed 11 instead of 7: other logits, other near-ties): french.wav under all four ids
+    if args.only == "real_audio_body_w11" or (not args.only and os.environ.get("TS_GOLDEN_BIG")):
+        tmp = tempfile.mkdtemp(prefix="ts_golden_")
+        vq_path = os.path.join(tmp, "vq.pth")
+        torch.save({"generator": {"g_body": T(synth.vqvae_state_dict(seed=11, in_dim=39)),
+                                  "g_hand": T(synth.vqvae_state_dict(seed=11, in_dim=90, salt=1))}}, vq_path)
+        cfg = json.load(open(os.path.join(REF, "config/body_pixel.json")))
+        cfg["Model"]["vq_path"] = vq_path
+        from trainer.config import Object
+        w = quiet(nets.s2g_body_pixel, argparse.Namespace(gpu="cpu", infer=True), Object(cfg))
+        w.load_state_dict({"generator": T(synth.pixelcnn_state_dict(seed=11)), "audioencoder": T(synth.audioencoder_state_dict(seed=11))})
+        w.generator.eval(); w.g_body.eval(); w.g_hand.eval(); w.audioencoder.eval()
+        wave = fe._load_mono_resampled(os.path.join(REF, "demo_audio", "french.wav"), 22000)
+        rows = fe.mfcc_float64(wave, 22000, hop_length=734).T.astype(np.float32)
+        ids = np.arange(4, dtype=np.int64)
+        with torch.no_grad():
+            feat = w.audioencoder(torch.from_numpy(rows[None]).transpose(1, 2), frame_num=0)
+            aud = feat.unsqueeze(-1).repeat(4, 1, 1, 2)
+            H = aud.shape[2]
+            codes, step_logits = greedy_reference(w.generator, torch.from_numpy(ids), aud, H)
+            body, _ = w.g_body.decode(b=4, w=H, latents=codes[..., 0])
+            hand, _ = w.g_hand.decode(b=4, w=H, latents=codes[..., 1])
+            poses = torch.cat([body, hand], dim=1).transpose(1, 2)
+        m = margins(step_logits.numpy()).reshape(4, H, 2)
+        print(f"real_audio_body_w11 french.wav: H {H} margin min/median {m.min():.2e} {np.median(m):.3f} under 1e-3: {int((m < 1e-3).sum())} of {m.size} uniq codes {codes.unique().numel()}")
+        save("real_audio_body_w11", weight_seed=np.asarray(11), codes=codes.numpy().astype(np.int16), margin=m.astype(np.float32), poses_id1=poses.numpy()[1])
+
     # ---- 7b. the face on the recordings: the reference wrapper's `generate(wav[None, None], frame)` (smplx_face.py:221-238: zero id)
     # and `infer_on_audio`-style one-hot id through `generator(...)`, frame = N * 30 // 16000 (smplx_face.py:203).  1st-page.wav is
     # native 16 kHz mono: int16 / 32768, no third-party step at all.  style.wav / french.wav: the 16 kHz samples the host twin of

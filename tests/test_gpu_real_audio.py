@@ -131,6 +131,31 @@ def test_body_on_recordings_wav_in(golden, tmp_path, name):
     assert_close_measured(f"real_audio.{t}.poses_wav_in", poses[0], g[t + "_poses"], 1e-4)
 
 
+def test_body_on_a_recording_second_weight_set(golden, tmp_path):
+    """french.wav's stored rows under a SECOND set of synthetic weights (seed 11: other logits, other near-ties) and all four speaker ids,
+    against what the reference's modules produced with those weights (`real_audio_body_w11`): 576 / 576 codes equal, poses within 1e-4."""
+    from nets.init_model import init_model
+    from talkshow_amd import _lib
+    from talkshow_amd.config import Object
+    g, gw = golden("real_audio_body"), golden("real_audio_body_w11")
+    seed = int(gw["weight_seed"])
+    vq_path = str(tmp_path / "vq.pth")
+    torch.save({"generator": {"g_body": synth.to_torch(synth.vqvae_state_dict(seed=seed, in_dim=39)),
+                              "g_hand": synth.to_torch(synth.vqvae_state_dict(seed=seed, in_dim=90, salt=1))}}, vq_path)
+    cfg = json.load(open(os.path.join(REPO, "config", "body_pixel.json")))
+    cfg["Model"]["vq_path"] = vq_path
+    w = init_model("s2g_body_pixel", argparse.Namespace(gpu=0, infer=True), Object(cfg))
+    w.load_state_dict({"generator": synth.to_torch(synth.pixelcnn_state_dict(seed=seed)),
+                       "audioencoder": synth.to_torch(synth.audioencoder_state_dict(seed=seed))})
+    rows, ref, margin = g["french_rows"], gw["codes"].astype(np.int64), gw["margin"]
+    c4, p4 = w.generate_batch(np.repeat(rows[None], 4, 0), np.arange(4, dtype=np.int64), mode=_lib.TS_SAMPLE_GREEDY)
+    equal, report = count_equal(c4.cpu().numpy(), ref, margin)
+    print(f"\nreal_audio_body_w11 french.wav (weights seed {seed}): greedy codes equal to the reference {equal} / {ref.size} "
+          f"(reference margins: min {margin.min():.2e}, {int((margin < NEAR_TIE_LOGIT).sum())} under {NEAR_TIE_LOGIT})")
+    assert equal == ref.size, f"{equal} / {ref.size}: " + "; ".join(report)
+    assert_close_measured("real_audio.french.poses_w11", p4.cpu().numpy()[1], gw["poses_id1"], 1e-4)
+
+
 def test_stochastic_decode_on_a_recording_vs_oracle(golden):
     """configs[3] on real speech: the reference's audio-encoder output for french.wav (golden) -> device PixelCNN decode with INJECTED
     uniforms and with the device Philox stream, against the oracle's full-grid `pixelcnn_generate(uniforms=...)` (the reference's
