@@ -773,6 +773,13 @@ class BodyJob:
             modes["one_batch_in_flight"] = {"what": "strict: one 32-clip batch at a time, one stream (= latency of a batch)",
                                             "ms_per_step": lat * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / lat}
             out["batch_latency_ms"] = lat * 1e3
+            # the same ONE batch with its VQ-encode half (which feeds nothing downstream) on a second stream, under the latency-bound chain
+            one2 = Engine(w, lib, _lib, pool[:1], B, T, 1, mfcc, gt, ids, rank, enc_streams=pool[1:2])
+            one2.warm(1)
+            lat2 = timed(lambda: one2.run_steps(1))
+            modes["one_batch_in_flight_encode_on_a_side_stream"] = {
+                "what": "strict: one 32-clip batch at a time; its VQ encode runs on a second stream beside audio encoder -> chain -> decode",
+                "ms_per_step": lat2 * 1e3, "frames_per_s": B * FRAMES_PER_CLIP / lat2}
             r01 = Engine(w, lib, _lib, pool[:4], B, T, 1, mfcc, gt, ids, rank)
             r01.warm(1)
             t4 = timed(lambda: r01.run_steps(16)) / 16
